@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: light curves/s for the feature sets built so far.
+
+One "step" = one pass of the selected feature kernels over one resident batch of synthetic
+light curves (SURVEY.md §8d generator).  Inputs are in HBM before the timed region starts.
+Multi-GPU: one process per GPU (torch.distributed / RCCL), objects sharded with no data-path
+collective, one gather of the feature rows to rank 0 per step; weak scaling (fixed objects/GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+NCOLS = {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65, "physics": 32, "gp2d": 27}
+
+
+def _cpu_worker(args):
+    name, csr, z, lo, hi = args
+    import oracle
+    return oracle.extract(name, csr, z, lo, hi).shape[0]
+
+
+def cpu_baseline(sets, lc, budget_s=15.0):
+    """Time the oracle (kind "port") on the host cores over a bounded sample of the same workload."""
+    import multiprocessing as mp
+    import oracle
+
+    cores = min(os.cpu_count() or 1, 16)
+    n_obj = len(lc["offsets"]) - 1
+    pilot = min(8, n_obj)
+    t0 = time.perf_counter()
+    for s in sets:
+        oracle.extract(s, lc, lc["z"], 0, pilot)
+    per_obj = (time.perf_counter() - t0) / pilot
+    sample = int(max(cores * 4, min(n_obj, budget_s * cores / max(per_obj, 1e-6))))
+    sample = min(sample, n_obj)
+    chunk = max(1, sample // (cores * 4))
+    jobs = [(s, lc, lc["z"], lo, min(lo + chunk, sample)) for s in sets for lo in range(0, sample, chunk)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_worker, jobs)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "light curves/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} objects of the benchmark batch, sets {'+'.join(sets)}, "
+                      f"multiprocessing.Pool({cores}) over the numpy/scipy oracle",
+            "single_core_est": 1.0 / per_obj}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--objects", type=int, default=125000, help="objects per GPU (config 5 = 1M over 8 GPUs)")
+    ap.add_argument("--sets", default="", help="comma list; default = every set the library implements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1000000)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mallorn_astrophysics_amd import _lib, synth
+    from mallorn_astrophysics_amd.columns import SET_NAMES
+    from mallorn_astrophysics_amd.engine import DeviceBatch, mask_of
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    lib = _lib.load()
+    impl = lib.lcfe_implemented_mask()
+    sets = [s for s in a.sets.split(",") if s] or [SET_NAMES[i] for i in range(8) if impl >> i & 1]
+    mask = mask_of(sets)
+    ncol = int(lib.lcfe_ncols(mask))
+
+    # every rank draws its own shard of the synthetic survey (objects are independent)
+    lc = synth.make_lightcurves(a.objects, seed=a.seed + rank)
+    batch = DeviceBatch(lc, z=lc["z"], device=local)
+    out = torch.empty((a.objects, ncol), dtype=torch.float64, device=batch.device)
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(prof=False):
+        r = batch.run(mask, out=out, prof=prof)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+        return r[2] if prof else None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    kernel_ms = np.zeros(8)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        p = step(prof=True)
+        kernel_ms += np.array(p["kernel_ms"])
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=batch.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_pts = int(lc["offsets"][-1])
+    kernel_ms /= a.steps
+    per_set = {s: float(kernel_ms[SET_NAMES.index(s)]) for s in sets}
+    # roofline of the statistics kernel if it ran (the kernel BASELINE.json names for the HBM
+    # roofline), else of the slowest kernel: algorithmic bytes = 25 B/point + 8 B/object offset
+    # + 8 B x F output columns, divided by the HIP-event time of that kernel.
+    rk = "stat" if "stat" in sets else max(per_set, key=per_set.get)
+    alg_bytes = 25 * n_pts + 8 * (a.objects + 1) + 8 * a.objects * NCOLS[rk] + (8 * a.objects if rk == "physics" else 0)
+    achieved = alg_bytes / (per_set[rk] * 1e-3) / 1e9 if per_set[rk] > 0 else 0.0
+    res = {
+        "metric": "light curves/sec", "value": a.objects * world * a.steps / dt, "unit": "light curves/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"config-5 shard: {'+'.join(sets)} feature sets ({ncol} columns) on "
+                               f"{a.objects} synthetic 6-band light curves per GPU ({n_pts} points on rank 0)",
+                   "objects_per_gpu": a.objects, "sets": sets, "parallelism": f"objects sharded over {world} GPU(s), "
+                   "one RCCL gather of the feature rows per step" if world > 1 else "single GPU"},
+        "kernel_ms": per_set,
+        "roofline": {"kernel": f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": per_set[rk]},
+    }
+    if not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(sets, lc)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

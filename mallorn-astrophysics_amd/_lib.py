@@ -1,0 +1,72 @@
+"""ctypes binding of liblcfe.so (include/lcfe.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblcfe.so")
+NUM_SETS = 8
+
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class LcfeStats(ctypes.Structure):
+    _fields_ = [("kernel_ms", ctypes.c_double * NUM_SETS), ("h2d_ms", ctypes.c_double),
+                ("d2h_ms", ctypes.c_double), ("bytes_in", ctypes.c_int64), ("bytes_out", ctypes.c_int64),
+                ("launches", ctypes.c_int32 * NUM_SETS), ("reserved", ctypes.c_int32)]
+
+
+class LcfeError(RuntimeError):
+    """Infrastructure failure (HIP error, bad argument) -- never a numerical fit failure."""
+
+
+_lib = None
+
+
+def load():
+    """Load liblcfe.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LcfeError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                        "(hipcc --offload-arch=gfx950); lcfe has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.lcfe_version.restype = ctypes.c_int
+    lib.lcfe_device_count.restype = ctypes.c_int
+    lib.lcfe_last_error.restype = ctypes.c_char_p
+    lib.lcfe_ncols.restype = ctypes.c_int64
+    lib.lcfe_ncols.argtypes = [ctypes.c_int]
+    lib.lcfe_nstatus.restype = ctypes.c_int64
+    lib.lcfe_nstatus.argtypes = [ctypes.c_int]
+    lib.lcfe_colname.restype = ctypes.c_char_p
+    lib.lcfe_colname.argtypes = [ctypes.c_int, ctypes.c_int64]
+    lib.lcfe_max_points.restype = ctypes.c_int64
+    lib.lcfe_implemented_mask.restype = ctypes.c_int
+    lib.lcfe_workspace_bytes.restype = ctypes.c_size_t
+    lib.lcfe_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+    lib.lcfe_extract.restype = ctypes.c_int
+    lib.lcfe_extract.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_i64p, c_f64p, c_f64p, c_f64p,
+                                 c_u8p, c_f64p, c_f64p, c_i32p, ctypes.POINTER(LcfeStats)]
+    lib.lcfe_extract_device.restype = ctypes.c_int
+    lib.lcfe_extract_device.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 9 + \
+                                       [ctypes.c_size_t, ctypes.POINTER(LcfeStats)]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LcfeError(f"{what}: {load().lcfe_last_error().decode()}")
+
+
+def stats_to_dict(st: LcfeStats):
+    return {"kernel_ms": list(st.kernel_ms), "h2d_ms": st.h2d_ms, "d2h_ms": st.d2h_ms,
+            "bytes_in": st.bytes_in, "bytes_out": st.bytes_out, "launches": list(st.launches)}

@@ -1,0 +1,66 @@
+// feature_sets.hpp -- dispatch of one object to a feature set, shared by the HIP kernels
+// (lcfe.hip) and the host simulation (tests/hostsim).
+#pragma once
+#include "stage.hpp"
+#include "stat.hpp"
+
+namespace lcfe {
+
+enum { SET_STAT = 0, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, NUM_SETS };
+
+LCFE_HD int set_ncols(int set) {
+    switch (set) {
+        case SET_STAT: return 123;
+        case SET_BAZIN: return 52;
+        case SET_POWERLAW: return 27;
+        case SET_TDE: return 25;
+        case SET_COLOR: return 83;
+        case SET_SHAPE: return 65;
+        case SET_PHYSICS: return 32;
+        case SET_GP2D: return 27;
+    }
+    return 0;
+}
+LCFE_HD int set_nstatus(int set) {
+    switch (set) {
+        case SET_BAZIN: return 12;
+        case SET_POWERLAW: return 54;
+        case SET_GP2D: return 4;
+    }
+    return 0;
+}
+
+// Wave-shared working memory (LDS on the device) of one object, per feature set.
+template <int SET, int CAP>
+struct SetLds;
+
+template <int CAP>
+struct SetLds<SET_STAT, CAP> {
+    ObjLds<CAP> obj;
+    StatScratch<CAP> stat;
+};
+
+// copy `ncol` wave-shared doubles to the object's output row (coalesced on the device)
+template <class W>
+LCFE_FN void store_row(const double* src, double* row, int ncol) {
+    for (int k = W::lane(); k < ncol; k += W::LANES) row[k] = src[k];
+}
+template <class W>
+LCFE_FN void fill_row_nan(double* row, int ncol) {
+    for (int k = W::lane(); k < ncol; k += W::LANES) row[k] = qnan();
+}
+
+template <class W, int SET, int CAP>
+struct RunSet;
+
+template <class W, int CAP>
+struct RunSet<W, SET_STAT, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
+        stage_object<W, CAP>(in, ws.obj);
+        stat_object<W, CAP>(ws.obj, ws.stat);
+        store_row<W>(ws.stat.out, row, STAT_NCOL);
+        W::sync();
+    }
+};
+
+}  // namespace lcfe

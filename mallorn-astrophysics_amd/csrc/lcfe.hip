@@ -1,0 +1,361 @@
+// lcfe.hip -- gfx950 kernels + C-ABI of liblcfe.so (see include/lcfe.h).
+//
+// Execution model: one light curve per 64-lane wavefront, one wavefront per workgroup, a
+// persistent grid that strides over the objects.  Per feature set the object's working set
+// (staged samples, sorted views, Jacobians, Gram matrices) lives in LDS; HBM is touched once for
+// the CSR slice and once for the output row.  Objects are binned into LDS tiers by point count
+// (CAP = 128 .. 2048): each tier is one launch that skips objects outside its window, so short
+// light curves run at high occupancy and long ones still fit.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lcfe.h"
+#include "feature_sets.hpp"
+
+using namespace lcfe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+    return 1;
+}
+int fail_msg(const std::string& m) {
+    g_err = m;
+    return 2;
+}
+#define HIP_TRY(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return fail(#expr, e_, __FILE__, __LINE__); \
+    } while (0)
+
+struct BatchView {
+    const int64_t* offsets;
+    const double* t;
+    const double* f;
+    const double* e;
+    const uint8_t* b;
+    const double* z;
+    int64_t n_obj;
+};
+
+// One launch = one (feature set, LDS tier): objects with lo < n <= CAP are processed, others are
+// left to the other tiers; n > hi_all (longer than the largest tier) gets NaN + status -100 from
+// the largest tier.
+template <int SET, int CAP>
+__global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_tier, double* out,
+                                                 int ld, int col0, int32_t* status, int st_ld,
+                                                 int st0) {
+    __shared__ SetLds<SET, CAP> ws;
+    using W = WaveDev;
+    const int ncol = set_ncols(SET);
+    const int nst = set_nstatus(SET);
+    for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
+        const int64_t s = B.offsets[i];
+        const int64_t n64 = B.offsets[i + 1] - s;
+        if (n64 <= lo) continue;
+        double* row = out + i * (int64_t)ld + col0;
+        int32_t* st = (status && nst) ? status + i * (int64_t)st_ld + st0 : nullptr;
+        if (n64 > CAP) {
+            if (last_tier) {
+                fill_row_nan<W>(row, ncol);
+                if (st) for (int k = W::lane(); k < nst; k += 64) st[k] = -100;
+            }
+            continue;
+        }
+        ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, B.z ? B.z[i] : qnan()};
+        RunSet<W, SET, CAP>::run(in, ws, row, st);
+    }
+}
+
+struct Tier { int cap; };
+const int kTiers[] = {128, 256, 512, 1024, 2048};
+constexpr int kNumTiers = 5;
+constexpr int kMaxPoints = 2048;
+
+int g_num_cu[16] = {0};
+
+int num_cus(int dev) {
+    if (dev < 0 || dev >= 16) return 256;
+    if (!g_num_cu[dev]) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cu[dev] = p.multiProcessorCount;
+        else g_num_cu[dev] = 256;
+    }
+    return g_num_cu[dev];
+}
+
+template <int SET, int CAP>
+int launch_tier(const BatchView& B, int lo, int last, double* out, int ld, int col0, int32_t* status,
+                int st_ld, int st0, hipStream_t stream, int dev) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, set_kernel<SET, CAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid > B.n_obj) grid = B.n_obj;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((set_kernel<SET, CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, lo, last, out,
+                       ld, col0, status, st_ld, st0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int SET>
+int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status,
+               int st_ld, int st0, hipStream_t stream, int dev, int* n_launch) {
+    // tiers needed: every tier whose window (prev_cap, cap] can contain an object, i.e. up to the
+    // first cap >= max_len; the last launched tier also NaN-fills objects longer than its cap.
+    int last = 0;
+    while (last < kNumTiers - 1 && kTiers[last] < max_len) ++last;
+    int lo = -1;   // n == 0 objects (never produced by the packer) still get a row from tier 0
+    for (int ti = 0; ti <= last; ++ti) {
+        const int is_last = (ti == last);
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_tier<SET, 128>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 1: rc = launch_tier<SET, 256>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 2: rc = launch_tier<SET, 512>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 3: rc = launch_tier<SET, 1024>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 4: rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+        lo = kTiers[ti];
+    }
+    return 0;
+}
+
+const char* kStat17[] = {"n_obs", "mean", "std", "min", "max", "median", "skew", "kurtosis", "amplitude",
+                         "mad", "iqr", "beyond_1std", "beyond_2std", "max_slope", "mean_snr", "time_span",
+                         "cadence_mean"};
+const char* kBands[] = {"u", "g", "r", "i", "z", "y", "all"};
+
+std::vector<std::string> build_names(int set) {
+    std::vector<std::string> v;
+    auto B = [&](int k) { return std::string(kBands[k]); };
+    switch (set) {
+        case SET_STAT:
+            for (int k = 0; k < 7; ++k)
+                for (auto s : kStat17) v.push_back(B(k) + "_" + s);
+            v.insert(v.end(), {"flux_ratio_g_r", "flux_ratio_r_i", "flux_ratio_i_z", "peak_band"});
+            break;
+        default:
+            for (int j = 0; j < set_ncols(set); ++j) v.push_back("set" + std::to_string(set) + "_" + std::to_string(j));
+    }
+    return v;
+}
+
+const std::vector<std::string>& names(int set) {
+    static std::vector<std::string> tab[NUM_SETS];
+    static bool init = false;
+    if (!init) {
+        for (int s = 0; s < NUM_SETS; ++s) tab[s] = build_names(s);
+        init = true;
+    }
+    return tab[set];
+}
+
+bool set_implemented(int set) { return set == SET_STAT; }
+
+}  // namespace
+
+extern "C" {
+
+int lcfe_version(void) { return 1; }
+
+int lcfe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* lcfe_last_error(void) { return g_err.c_str(); }
+
+int64_t lcfe_max_points(void) { return kMaxPoints; }
+
+int lcfe_implemented_mask(void) {
+    int m = 0;
+    for (int s = 0; s < NUM_SETS; ++s)
+        if (set_implemented(s)) m |= 1 << s;
+    return m;
+}
+
+int64_t lcfe_ncols(int mask) {
+    int64_t n = 0;
+    for (int s = 0; s < NUM_SETS; ++s)
+        if (mask & (1 << s)) n += set_ncols(s);
+    return n;
+}
+
+int64_t lcfe_nstatus(int mask) {
+    int64_t n = 0;
+    for (int s = 0; s < NUM_SETS; ++s)
+        if (mask & (1 << s)) n += set_nstatus(s);
+    return n;
+}
+
+const char* lcfe_colname(int mask, int64_t j) {
+    if (j < 0) return nullptr;
+    for (int s = 0; s < NUM_SETS; ++s) {
+        if (!(mask & (1 << s))) continue;
+        if (j < set_ncols(s)) return names(s)[(size_t)j].c_str();
+        j -= set_ncols(s);
+    }
+    return nullptr;
+}
+
+size_t lcfe_workspace_bytes(int, int64_t, int64_t) { return 256; }
+
+int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int64_t n_points,
+                        int64_t max_len, const int64_t* d_offsets, const double* d_t, const double* d_flux,
+                        const double* d_err, const uint8_t* d_band, const double* d_z, double* d_out,
+                        int32_t* d_status, void* d_workspace, size_t workspace_bytes, lcfe_stats* prof) {
+    (void)d_workspace;
+    (void)workspace_bytes;
+    g_err.clear();
+    if (mask <= 0 || mask > LCFE_MASK_ALL) return fail_msg("lcfe_extract_device: empty or unknown feature-set mask");
+    for (int s = 0; s < NUM_SETS; ++s)
+        if ((mask & (1 << s)) && !set_implemented(s))
+            return fail_msg("lcfe_extract_device: feature set " + std::to_string(s) + " is not built into this library");
+    if (n_obj < 0 || n_points < 0 || max_len < 0) return fail_msg("lcfe_extract_device: negative size");
+    if (n_obj == 0) return 0;
+    if (!d_offsets || !d_out || (n_points > 0 && (!d_t || !d_flux || !d_err || !d_band)))
+        return fail_msg("lcfe_extract_device: null array");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipStream_t stream = (hipStream_t)stream_;
+    BatchView B{d_offsets, d_t, d_flux, d_err, d_band, d_z, n_obj};
+    const int ld = (int)lcfe_ncols(mask);
+    const int st_ld = (int)lcfe_nstatus(mask);
+    if (prof) {
+        memset(prof, 0, sizeof *prof);
+        prof->bytes_in = 25 * n_points + 8 * (n_obj + 1) + (d_z ? 8 * n_obj : 0);
+        prof->bytes_out = 8 * n_obj * (int64_t)ld;
+    }
+    hipEvent_t ev[NUM_SETS + 1];
+    if (prof)
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    int col0 = 0, st0 = 0, ne = 0;
+    int used[NUM_SETS];
+    for (int s = 0; s < NUM_SETS; ++s) {
+        if (!(mask & (1 << s))) continue;
+        if (prof) HIP_TRY(hipEventRecord(ev[ne], stream));
+        int nl = 0, rc = 0;
+        switch (s) {
+            case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+        }
+        if (rc) return rc;
+        if (prof) prof->launches[s] = nl;
+        used[ne++] = s;
+        col0 += set_ncols(s);
+        st0 += set_nstatus(s);
+    }
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[ne], stream));
+        HIP_TRY(hipEventSynchronize(ev[ne]));
+        for (int k = 0; k < ne; ++k) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            prof->kernel_ms[used[k]] = ms;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return 0;
+}
+
+int lcfe_extract(int mask, int device, int64_t n_obj, const int64_t* offsets, const double* t,
+                 const double* flux, const double* err, const uint8_t* band, const double* z, double* out,
+                 int32_t* status, lcfe_stats* prof) {
+    g_err.clear();
+    if (n_obj < 0) return fail_msg("lcfe_extract: negative n_obj");
+    if (n_obj == 0) return 0;
+    if (!offsets || !out) return fail_msg("lcfe_extract: null array");
+    if (lcfe_device_count() < 1) return fail_msg("lcfe_extract: no HIP device visible (liblcfe has no CPU fallback)");
+    // host-side validation: a malformed CSR must never reach a kernel
+    if (offsets[0] != 0) return fail_msg("lcfe_extract: offsets[0] != 0");
+    int64_t max_len = 0;
+    for (int64_t i = 0; i < n_obj; ++i) {
+        const int64_t n = offsets[i + 1] - offsets[i];
+        if (n < 0) return fail_msg("lcfe_extract: offsets not non-decreasing");
+        if (n > max_len) max_len = n;
+    }
+    const int64_t np = offsets[n_obj];
+    if (np > 0 && (!t || !flux || !err || !band)) return fail_msg("lcfe_extract: null sample array");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    const int64_t ld = lcfe_ncols(mask), st_ld = lcfe_nstatus(mask);
+    if (ld <= 0) return fail_msg("lcfe_extract: empty feature-set mask");
+    int64_t* d_off = nullptr;
+    double *d_t = nullptr, *d_f = nullptr, *d_e = nullptr, *d_z = nullptr, *d_out = nullptr;
+    uint8_t* d_b = nullptr;
+    int32_t* d_st = nullptr;
+    void* d_ws = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        void* ptrs[] = {d_off, d_t, d_f, d_e, d_b, d_z, d_out, d_st, d_ws};
+        for (void* p : ptrs) (void)hipFree(p);
+    };
+#define TRY_OR_CLEAN(expr)                                         \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) {                                    \
+            rc = fail(#expr, e_, __FILE__, __LINE__);              \
+            cleanup();                                             \
+            return rc;                                             \
+        }                                                          \
+    } while (0)
+    hipEvent_t e0, e1, e2, e3;
+    TRY_OR_CLEAN(hipEventCreate(&e0)); TRY_OR_CLEAN(hipEventCreate(&e1));
+    TRY_OR_CLEAN(hipEventCreate(&e2)); TRY_OR_CLEAN(hipEventCreate(&e3));
+    const size_t npa = (size_t)(np > 0 ? np : 1);
+    TRY_OR_CLEAN(hipMalloc(&d_off, sizeof(int64_t) * (n_obj + 1)));
+    TRY_OR_CLEAN(hipMalloc(&d_t, 8 * npa));
+    TRY_OR_CLEAN(hipMalloc(&d_f, 8 * npa));
+    TRY_OR_CLEAN(hipMalloc(&d_e, 8 * npa));
+    TRY_OR_CLEAN(hipMalloc(&d_b, npa));
+    if (z) TRY_OR_CLEAN(hipMalloc(&d_z, 8 * n_obj));
+    TRY_OR_CLEAN(hipMalloc(&d_out, 8 * (size_t)n_obj * ld));
+    if (st_ld > 0) TRY_OR_CLEAN(hipMalloc(&d_st, 4 * (size_t)n_obj * st_ld));
+    const size_t wsb = lcfe_workspace_bytes(mask, n_obj, np);
+    TRY_OR_CLEAN(hipMalloc(&d_ws, wsb));
+    TRY_OR_CLEAN(hipEventRecord(e0, 0));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n_obj + 1), hipMemcpyHostToDevice, 0));
+    if (np > 0) {
+        TRY_OR_CLEAN(hipMemcpyAsync(d_t, t, 8 * np, hipMemcpyHostToDevice, 0));
+        TRY_OR_CLEAN(hipMemcpyAsync(d_f, flux, 8 * np, hipMemcpyHostToDevice, 0));
+        TRY_OR_CLEAN(hipMemcpyAsync(d_e, err, 8 * np, hipMemcpyHostToDevice, 0));
+        TRY_OR_CLEAN(hipMemcpyAsync(d_b, band, np, hipMemcpyHostToDevice, 0));
+    }
+    if (z) TRY_OR_CLEAN(hipMemcpyAsync(d_z, z, 8 * n_obj, hipMemcpyHostToDevice, 0));
+    if (d_st) TRY_OR_CLEAN(hipMemsetAsync(d_st, 0, 4 * (size_t)n_obj * st_ld, 0));
+    TRY_OR_CLEAN(hipEventRecord(e1, 0));
+    lcfe_stats local;
+    rc = lcfe_extract_device(mask, -1, nullptr, n_obj, np, max_len, d_off, d_t, d_f, d_e, d_b, d_z, d_out, d_st,
+                             d_ws, wsb, prof ? &local : nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY_OR_CLEAN(hipEventRecord(e2, 0));
+    TRY_OR_CLEAN(hipMemcpyAsync(out, d_out, 8 * (size_t)n_obj * ld, hipMemcpyDeviceToHost, 0));
+    if (status && d_st) TRY_OR_CLEAN(hipMemcpyAsync(status, d_st, 4 * (size_t)n_obj * st_ld, hipMemcpyDeviceToHost, 0));
+    TRY_OR_CLEAN(hipEventRecord(e3, 0));
+    TRY_OR_CLEAN(hipStreamSynchronize(0));
+    if (prof) {
+        *prof = local;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1); prof->h2d_ms = ms;
+        (void)hipEventElapsedTime(&ms, e2, e3); prof->d2h_ms = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+    cleanup();
+    return 0;
+}
+
+}  // extern "C"

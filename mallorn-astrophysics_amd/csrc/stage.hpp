@@ -1,0 +1,127 @@
+// stage.hpp -- bring one object's CSR slice into LDS and derive the views every extractor needs.
+//
+// The reference does, per object and per band, ``obj_lc[obj_lc['Filter'] == band]
+// .sort_values('Time (MJD)')`` (bazin_fitting.py:195, tde_physics.py:39, lightcurve_shape.py:192,
+// physics_based.py:308) -- a boolean filter plus a sort per band per extractor.  Here the slice is
+// read once (coalesced 8-byte lanes) and a single band-partitioned, time-sorted copy is built in
+// LDS; the file-order arrays are kept because several features depend on row order
+// (SURVEY.md §8a "order / tie traps").
+//
+// Sort rule: stable by (time, file index) -- pandas' default quicksort leaves ties undefined.
+#pragma once
+#include "wave.hpp"
+
+namespace lcfe {
+
+template <int CAP>
+struct ObjLds {
+    // file order
+    double t[CAP], f[CAP], e[CAP];
+    // band-partitioned (u,g,r,i,z,y segments), each segment sorted by (t, file index)
+    double bt[CAP], bf[CAP], be[CAP];
+    unsigned short bidx[CAP];   // file index of each band-sorted element
+    unsigned char b[CAP];       // file order band codes (0..5, 255 unknown)
+    int boff[8];                // boff[k]..boff[k+1] = segment of band k; boff[6] = #known-band points
+    int n;                      // number of points
+    int sorted;                 // 1 if file order is already non-decreasing in time
+};
+
+// Fill `L` from the global slice.  All lanes of the wave must call it.
+template <class W, int CAP>
+LCFE_FN void stage_object(const ObjIn& in, ObjLds<CAP>& L) {
+    const int lane = W::lane();
+    const int n = in.n;
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = true;
+    for (int i = lane; i < n; i += W::LANES) {
+        double ti = in.t[i];
+        L.t[i] = ti;
+        L.f[i] = in.f[i];
+        L.e[i] = in.e[i];
+        unsigned char bb = in.b[i];
+        L.b[i] = bb;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cnt[k] += (bb == k);
+        if (i + 1 < n) ok = ok && (ti <= in.t[i + 1]);
+    }
+    const bool sorted = W::all(ok);
+    int off = 0;
+    if (lane == 0) L.boff[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        cnt[k] = W::sum(cnt[k]);
+        off += cnt[k];
+        if (lane == 0) L.boff[k + 1] = off;
+    }
+    if (lane == 0) { L.boff[7] = off; L.n = n; L.sorted = sorted ? 1 : 0; }
+    W::sync();
+    if (sorted) {
+        // stable partition: position = segment start + number of earlier rows of the same band
+        int run[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) run[k] = L.boff[k];
+        for (int base = 0; base < n; base += W::LANES) {
+            const int i = base + lane;
+            const int bb = (i < n) ? (int)L.b[i] : 255;
+            int pos = -1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                unsigned long long m = W::ballot(bb == k);
+                if (bb == k) pos = run[k] + W::prefix(m);
+                run[k] += popcll(m);
+            }
+            if (pos >= 0) {
+                L.bt[pos] = L.t[i];
+                L.bf[pos] = L.f[i];
+                L.be[pos] = L.e[i];
+                L.bidx[pos] = (unsigned short)i;
+            }
+        }
+    } else {
+        // general path: rank of (t, i) among the rows of the same band
+        for (int i = lane; i < n; i += W::LANES) {
+            const int bb = L.b[i];
+            if (bb >= 6) continue;
+            const double ti = L.t[i];
+            int r = 0;
+            for (int j = 0; j < n; ++j) {
+                const double tj = L.t[j];
+                r += (L.b[j] == bb) && ((tj < ti) || (tj == ti && j < i));
+            }
+            const int pos = L.boff[bb] + r;
+            L.bt[pos] = ti;
+            L.bf[pos] = L.f[i];
+            L.be[pos] = L.e[i];
+            L.bidx[pos] = (unsigned short)i;
+        }
+    }
+    W::sync();
+}
+
+// numpy.argmax semantics on a (wave-shared) array: index of the FIRST maximum; a NaN counts as
+// the maximum (numpy propagates the first NaN).  Returns -1 for m == 0.  Uniform result.
+template <class W>
+LCFE_FN int wave_argmax_first(const double* x, int m) {
+    const int lane = W::lane();
+    double best = 0.0;
+    int bi = 0x7fffffff;
+    bool have = false;
+    for (int i = lane; i < m; i += W::LANES) {
+        const double v = x[i];
+        if (!have) { best = v; bi = i; have = true; }
+        else if (!is_nan(best) && (is_nan(v) || v > best)) { best = v; bi = i; }
+    }
+    // reduce (value desc, NaN first, index asc)
+    // step 1: is there a NaN anywhere?  then answer = min index of a NaN
+    const bool has_nan = W::any(have && is_nan(best));
+    if (has_nan) {
+        int c = (have && is_nan(best)) ? bi : 0x7fffffff;
+        return W::min(c);
+    }
+    if (m <= 0) return -1;
+    const double mx = W::max(have ? best : -__builtin_inf());
+    int c = (have && best == mx) ? bi : 0x7fffffff;
+    return W::min(c);
+}
+
+}  // namespace lcfe

@@ -1,0 +1,118 @@
+// wave.hpp -- the one-object-per-wavefront execution policy.
+//
+// Every feature kernel is written as a function template over a policy W that provides the
+// wave-level primitives (lane id, reductions, ballot, broadcast, LDS fence).  On the GPU W is
+// WaveDev: a 64-lane gfx950 wavefront, one workgroup = one wavefront (so the workgroup barrier
+// is the wave-level LDS fence).  tests/hostsim compiles the same templates with WaveHost
+// (LANES = 1, reductions are identities) so the arithmetic can be checked on the CPU-only
+// build container under sanitizers; that build is test infrastructure and is never loaded by
+// the product path.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LCFE_FN __device__ __forceinline__
+#define LCFE_FN_NOINLINE __device__ __noinline__
+#define LCFE_HD __host__ __device__ inline
+#else
+#define LCFE_FN inline
+#define LCFE_FN_NOINLINE inline
+#define LCFE_HD inline
+#endif
+
+namespace lcfe {
+
+#if defined(__HIPCC__)
+struct WaveDev {
+    static constexpr int LANES = 64;
+    static __device__ __forceinline__ int lane() { return threadIdx.x; }
+    // LDS fence between cross-lane producer/consumer phases (workgroup == one wave)
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+
+    static __device__ __forceinline__ double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+    static __device__ __forceinline__ double sum(double v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    static __device__ __forceinline__ double max(double v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ double min(double v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = (o < v) ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ int sum(int v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    static __device__ __forceinline__ int max(int v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ int min(int v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = (o < v) ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+    static __device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0ull; }
+    static __device__ __forceinline__ bool all(bool p) { return __ballot(!p) == 0ull; }
+    // number of set bits of `mask` strictly below this lane
+    static __device__ __forceinline__ int prefix(unsigned long long mask) {
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    }
+    static __device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+    static __device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
+};
+#endif
+
+struct WaveHost {
+    static constexpr int LANES = 1;
+    static int lane() { return 0; }
+    static void sync() {}
+    static double sum(double v) { return v; }
+    static double max(double v) { return v; }
+    static double min(double v) { return v; }
+    static int sum(int v) { return v; }
+    static int max(int v) { return v; }
+    static int min(int v) { return v; }
+    static unsigned long long ballot(bool p) { return p ? 1ull : 0ull; }
+    static bool any(bool p) { return p; }
+    static bool all(bool p) { return p; }
+    static int prefix(unsigned long long) { return 0; }
+    static double bcast(double v, int) { return v; }
+    static int bcast(int v, int) { return v; }
+};
+
+LCFE_FN int popcll(unsigned long long m) { return __builtin_popcountll(m); }
+
+// quiet NaN without relying on host/device library differences
+LCFE_FN double qnan() { return __builtin_nan(""); }
+LCFE_FN bool is_nan(double x) { return x != x; }
+
+// Order-preserving map of a double onto uint64 (numpy's sort order: -inf < ... < +inf < NaN).
+LCFE_FN uint64_t sort_key(double x) {
+    if (x != x) return ~0ull;                       // every NaN sorts last
+    uint64_t u = (uint64_t)__builtin_bit_cast(long long, x);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// One object's slice of the CSR batch (global memory) + scalars.
+struct ObjIn {
+    const double* t;
+    const double* f;
+    const double* e;
+    const uint8_t* b;
+    int n;
+    double z;
+};
+
+}  // namespace lcfe

@@ -1,0 +1,49 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE: the kernel templates of mallorn-astrophysics_amd/csrc
+// compiled for the host with the one-lane WaveHost policy (reductions are identities), so the
+// feature arithmetic can be checked against the oracle in the GPU-less build container and run
+// under -fsanitize=address,undefined.  Never loaded by the product package.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+
+#include "../../mallorn-astrophysics_amd/csrc/feature_sets.hpp"
+
+using namespace lcfe;
+
+#ifndef HOSTSIM_CAP
+#define HOSTSIM_CAP 2048
+#endif
+
+extern "C" int hostsim_max_points() { return HOSTSIM_CAP; }
+
+template <int SET>
+static void run_all(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux,
+                    const double* err, const uint8_t* band, const double* z, double* out,
+                    int32_t* status) {
+    using W = WaveHost;
+    auto ws = std::make_unique<SetLds<SET, HOSTSIM_CAP>>();
+    const int ncol = set_ncols(SET);
+    const int nst = set_nstatus(SET);
+    for (int64_t i = 0; i < n_obj; ++i) {
+        const int64_t s = offsets[i];
+        const int n = (int)(offsets[i + 1] - s);
+        double* row = out + i * ncol;
+        int32_t* st = (status && nst) ? status + i * nst : nullptr;
+        if (n > HOSTSIM_CAP) {
+            fill_row_nan<W>(row, ncol);
+            for (int k = 0; k < nst; ++k) if (st) st[k] = -100;
+            continue;
+        }
+        ObjIn in{t + s, flux + s, err + s, band + s, n, z ? z[i] : qnan()};
+        RunSet<W, SET, HOSTSIM_CAP>::run(in, *ws, row, st);
+    }
+}
+
+extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, const double* t,
+                               const double* flux, const double* err, const uint8_t* band,
+                               const double* z, double* out, int32_t* status) {
+    switch (set) {
+        case SET_STAT: run_all<SET_STAT>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        default: return 1;
+    }
+}

@@ -1,0 +1,112 @@
+"""Parity tests proper: the HIP path through the C-ABI against the golden fixtures (real
+reference outputs) and against the oracle on seeded synthetic inputs.  Need an MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from conftest import load_golden
+from mallorn_astrophysics_amd import synth
+from mallorn_astrophysics_amd.columns import COLUMNS, SET_NAMES, STAT_INT_COLUMNS
+from mallorn_astrophysics_amd.engine import extract_csr
+
+pytestmark = pytest.mark.gpu
+
+# tolerance written per set: BASELINE.md asks <= 1e-4 relative on fitted parameters and bit-exact
+# counts; closed-form statistics are held much tighter.
+TOL = {"stat": dict(rtol=1e-9, atol=1e-12)}
+INT = {"stat": STAT_INT_COLUMNS}
+SETS = list(TOL)
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_golden(name, golden_inputs):
+    ref = load_golden(name)
+    got = extract_csr(name, golden_inputs, z=golden_inputs["z"])
+    bad = parity.compare(got, ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_seeded_vs_oracle(name):
+    lc = synth.make_lightcurves(300, seed=1234)
+    got = extract_csr(name, lc, z=lc["z"])
+    ref = oracle.extract(name, lc, lc["z"])
+    bad = parity.compare(got, ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_lds_tiers_and_long_objects(name):
+    """Objects of 100..2048 points exercise every LDS tier; > 2048 points -> NaN row (documented)."""
+    rng = np.random.default_rng(5)
+    objs = []
+    for n in (100, 128, 129, 256, 257, 500, 512, 513, 1000, 1024, 1500, 2048, 2049, 3000):
+        t = np.sort(59000 + rng.uniform(0, 800, n))
+        f = 30 * np.exp(-0.5 * ((t - 59300) / 40) ** 2) + rng.normal(0, 1, n)
+        objs.append((t, f, np.full(n, 1.0), rng.choice(6, n)))
+    lc = synth.from_objects(objs)
+    got = extract_csr(name, lc, z=lc["z"])
+    n_ok = 12
+    sub = {k: (v[:lc["offsets"][n_ok]] if k in ("t", "flux", "err", "band") else v) for k, v in lc.items()}
+    sub["offsets"] = lc["offsets"][:n_ok + 1]
+    ref = oracle.extract(name, sub, lc["z"][:n_ok])
+    bad = parity.compare(got[:n_ok], ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
+    assert not bad, "\n".join(bad)
+    assert np.isnan(got[n_ok:]).all()
+
+
+def test_unsorted_rows_match(golden_inputs):
+    """Shuffling the rows of every object must not change the statistics (sort paths on device)."""
+    rng = np.random.default_rng(11)
+    lc = synth.make_lightcurves(64, seed=77)
+    sh = {k: v.copy() for k, v in lc.items()}
+    for i in range(64):
+        s, e = lc["offsets"][i], lc["offsets"][i + 1]
+        p = rng.permutation(e - s) + s
+        for k in ("t", "flux", "err", "band"):
+            sh[k][s:e] = lc[k][p]
+    a = extract_csr("stat", lc)
+    b = extract_csr("stat", sh)
+    ref = oracle.extract("stat", sh)
+    bad = parity.compare(b, ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+    bad = parity.compare(b, a, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+
+
+def test_empty_batch_and_single_object():
+    lc = synth.make_lightcurves(1, seed=2)
+    got = extract_csr("stat", lc)
+    assert got.shape == (1, 123)
+    empty = {"offsets": np.zeros(1, np.int64), "t": np.zeros(0), "flux": np.zeros(0), "err": np.zeros(0),
+             "band": np.zeros(0, np.uint8)}
+    assert extract_csr("stat", empty).shape == (0, 123)
+
+
+def test_dataframe_boundary_statistical(golden_inputs):
+    """extract_statistical_features(DataFrame) -> DataFrame, as the reference's callers use it."""
+    from mallorn_astrophysics_amd.features.statistical import extract_statistical_features
+    ids = synth.object_ids(len(golden_inputs["offsets"]) - 1)
+    df, meta = synth.to_dataframe(golden_inputs, ids)
+    want = [ids[5], "absent_id", ids[0], ids[260]]
+    out = extract_statistical_features(df, want)
+    assert list(out["object_id"]) == [ids[5], ids[0], ids[260]]
+    assert list(out.columns) == ["object_id"] + COLUMNS["stat"]
+    for c in STAT_INT_COLUMNS:
+        assert out[c].dtype == np.int64
+    ref = load_golden("stat")[[5, 0, 260]]
+    bad = parity.compare(out[COLUMNS["stat"]].to_numpy(float), ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS,
+                         rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+
+
+def test_device_resident_path_matches_host_path():
+    import torch
+    from mallorn_astrophysics_amd.engine import DeviceBatch
+    lc = synth.make_lightcurves(500, seed=9)
+    host = extract_csr("stat", lc)
+    db = DeviceBatch(lc, z=lc["z"], device=0)
+    out, _ = db.run("stat")
+    torch.cuda.synchronize()
+    assert np.array_equal(np.nan_to_num(out.cpu().numpy(), nan=-7.0), np.nan_to_num(host, nan=-7.0))

@@ -1,0 +1,22 @@
+"""The kernel templates compiled for the host (one-lane wave) against the golden fixtures.
+Exercises the kernels' arithmetic and indexing on the CPU-only container; the -m gpu tests run
+the same comparison through the C-ABI on the device."""
+import numpy as np
+import pytest
+
+import hostsim_lib
+import parity
+from conftest import load_golden
+from mallorn_astrophysics_amd.columns import COLUMNS, SET_NAMES, STAT_INT_COLUMNS
+
+# relative tolerance per set (floats); near-zero moments get an absolute floor
+TOL = {"stat": dict(rtol=1e-9, atol=1e-12)}
+
+
+@pytest.mark.parametrize("name", list(TOL))
+def test_hostsim_matches_reference(name, golden_inputs):
+    ref = load_golden(name)
+    got, _ = hostsim_lib.extract(SET_NAMES.index(name), golden_inputs, golden_inputs["z"], ncol=ref.shape[1])
+    bad = parity.compare(got, ref, COLUMNS[name], int_cols=STAT_INT_COLUMNS if name == "stat" else (),
+                         label=name, **TOL[name])
+    assert not bad, "\n".join(bad)
