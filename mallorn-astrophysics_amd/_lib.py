@@ -29,6 +29,31 @@ class LcfeError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so.7``; ``liblcfe.so`` links the same
+    SONAME from /opt/rocm.  Whichever is mapped first serves the whole process, and torch cannot
+    see the GPU through a runtime it was not built with.  When torch is installed (it is the
+    allocator / stream / RCCL plumbing of the device-resident path) map its runtime first, without
+    paying for ``import torch``."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load liblcfe.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
     global _lib
@@ -37,6 +62,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LcfeError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                         "(hipcc --offload-arch=gfx950); lcfe has no CPU fallback")
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     lib.lcfe_version.restype = ctypes.c_int
     lib.lcfe_device_count.restype = ctypes.c_int

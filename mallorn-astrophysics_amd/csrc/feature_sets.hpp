@@ -3,6 +3,7 @@
 #pragma once
 #include "stage.hpp"
 #include "stat.hpp"
+#include "fits.hpp"
 
 namespace lcfe {
 
@@ -40,6 +41,18 @@ struct SetLds<SET_STAT, CAP> {
     StatScratch<CAP> stat;
 };
 
+template <int CAP>
+struct SetLds<SET_BAZIN, CAP> {
+    ObjLds<CAP> obj;
+    BazinLds<CAP> fit;
+};
+
+template <int CAP>
+struct SetLds<SET_POWERLAW, CAP> {
+    ObjLds<CAP> obj;
+    PowerlawLds<CAP> fit;
+};
+
 // copy `ncol` wave-shared doubles to the object's output row (coalesced on the device)
 template <class W>
 LCFE_FN void store_row(const double* src, double* row, int ncol) {
@@ -59,6 +72,26 @@ struct RunSet<W, SET_STAT, CAP> {
         stage_object<W, CAP>(in, ws.obj);
         stat_object<W, CAP>(ws.obj, ws.stat);
         store_row<W>(ws.stat.out, row, STAT_NCOL);
+        W::sync();
+    }
+};
+
+template <class W, int CAP>
+struct RunSet<W, SET_BAZIN, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_BAZIN, CAP>& ws, double* row, int32_t* st) {
+        stage_object<W, CAP>(in, ws.obj);
+        bazin_object<W, CAP>(ws.obj, ws.fit, st);
+        store_row<W>(ws.fit.out, row, BAZIN_NCOL);
+        W::sync();
+    }
+};
+
+template <class W, int CAP>
+struct RunSet<W, SET_POWERLAW, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_POWERLAW, CAP>& ws, double* row, int32_t* st) {
+        stage_object<W, CAP>(in, ws.obj);
+        powerlaw_object<W, CAP>(ws.obj, ws.fit, st);
+        store_row<W>(ws.fit.out, row, POWERLAW_NCOL);
         W::sync();
     }
 };

@@ -109,13 +109,19 @@ int launch_tier(const BatchView& B, int lo, int last, double* out, int ld, int c
     return 0;
 }
 
+// largest LDS tier a set's working memory fits in (160 KiB per workgroup)
+template <int SET>
+constexpr int max_tier() {
+    return (SET == SET_BAZIN || SET == SET_POWERLAW) ? 3 : 4;
+}
+
 template <int SET>
 int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status,
                int st_ld, int st0, hipStream_t stream, int dev, int* n_launch) {
     // tiers needed: every tier whose window (prev_cap, cap] can contain an object, i.e. up to the
     // first cap >= max_len; the last launched tier also NaN-fills objects longer than its cap.
     int last = 0;
-    while (last < kNumTiers - 1 && kTiers[last] < max_len) ++last;
+    while (last < max_tier<SET>() && kTiers[last] < max_len) ++last;
     int lo = -1;   // n == 0 objects (never produced by the packer) still get a row from tier 0
     for (int ti = 0; ti <= last; ++ti) {
         const int is_last = (ti == last);
@@ -125,7 +131,10 @@ int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col
             case 1: rc = launch_tier<SET, 256>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
             case 2: rc = launch_tier<SET, 512>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
             case 3: rc = launch_tier<SET, 1024>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
-            case 4: rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 4:
+                if constexpr (max_tier<SET>() >= 4)
+                    rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev);
+                break;
         }
         if (rc) return rc;
         ++*n_launch;
@@ -148,6 +157,22 @@ std::vector<std::string> build_names(int set) {
                 for (auto s : kStat17) v.push_back(B(k) + "_" + s);
             v.insert(v.end(), {"flux_ratio_g_r", "flux_ratio_r_i", "flux_ratio_i_z", "peak_band"});
             break;
+        case SET_BAZIN: {
+            const char* p8[] = {"bazin_A", "bazin_t0", "bazin_tau_rise", "bazin_tau_fall", "bazin_B",
+                                "bazin_fit_chi2", "bazin_rise_fall_ratio", "bazin_peak_flux"};
+            for (int k = 0; k < 6; ++k)
+                for (auto s : p8) v.push_back(B(k) + "_" + s);
+            v.insert(v.end(), {"bazin_rise_consistency", "bazin_fall_consistency", "bazin_avg_fit_chi2",
+                               "bazin_fit_quality_dispersion"});
+            break;
+        }
+        case SET_POWERLAW: {
+            const char* md[] = {"powerlaw_5_3", "powerlaw_1", "powerlaw_1_5", "powerlaw_2", "powerlaw_2_5",
+                                "powerlaw_3", "powerlaw_0_5", "exponential", "linear"};
+            for (int k = 1; k <= 3; ++k)
+                for (auto s : md) v.push_back(B(k) + "_" + s + "_r2");
+            break;
+        }
         default:
             for (int j = 0; j < set_ncols(set); ++j) v.push_back("set" + std::to_string(set) + "_" + std::to_string(j));
     }
@@ -164,7 +189,7 @@ const std::vector<std::string>& names(int set) {
     return tab[set];
 }
 
-bool set_implemented(int set) { return set == SET_STAT; }
+bool set_implemented(int set) { return set == SET_STAT || set == SET_BAZIN || set == SET_POWERLAW; }
 
 }  // namespace
 
@@ -253,6 +278,8 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         int nl = 0, rc = 0;
         switch (s) {
             case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
         }
         if (rc) return rc;
         if (prof) prof->launches[s] = nl;

@@ -82,8 +82,41 @@ def main():
         nfev_log.append(r[2]["nfev"])
         return r[0], r[1]
     bazin_fitting.curve_fit = cf
-    save("bazin", bazin_fitting.extract_bazin_features(df, ids), nfev=np.array(nfev_log))
+    bz = bazin_fitting.extract_bazin_features(df, ids)
     bazin_fitting.curve_fit = real_cf
+    nfev = np.array(nfev_log)
+
+    # The bounded fits stop at ftol = 1e-8 on the COST, so in flat directions the parameters are only
+    # fixed to ~1e-4 and the path depends on rounding.  To tell well-conditioned fits from chaotic
+    # ones without circularity, the reference is also run on inputs whose fluxes are moved by one
+    # ulp (x (1 +- 2.2e-16)): fits that scipy itself does not reproduce are not held to 1e-4.
+    def perturbed(seed):
+        rng = np.random.default_rng(seed)
+        d2 = df.copy()
+        d2["Flux"] = d2["Flux"].to_numpy() * (1 + rng.choice([-1.0, 1.0], len(d2)) * 2.220446049250313e-16)
+        return d2
+    pert = [perturbed(1), perturbed(2)]
+
+    # Second probe: the last bit of the model evaluation.  exp()/pow() of numpy, glibc and the GPU
+    # differ by <= 1 ulp; through the finite-difference Jacobian that is a ~1e-8 relative change of J
+    # (the flux probe cannot show it: y cancels in f(x+h) - f(x)).  The model function handed to
+    # curve_fit is wrapped so that every value it returns is moved by -1/0/+1 ulp at random.
+    def noisy(fn, seed):
+        rng = np.random.default_rng(seed)
+
+        def wrapped(t, *a):
+            v = np.asarray(fn(t, *a), float)
+            return v * (1.0 + rng.integers(-1, 2, v.shape) * 2.220446049250313e-16)
+        return wrapped
+
+    extra = {"out_p1": bazin_fitting.extract_bazin_features(pert[0], ids)[COLUMNS["bazin"]].to_numpy(float),
+             "out_p2": bazin_fitting.extract_bazin_features(pert[1], ids)[COLUMNS["bazin"]].to_numpy(float)}
+    real_fn = bazin_fitting.bazin_function
+    for q in (1, 2, 3):
+        bazin_fitting.bazin_function = noisy(real_fn, 100 + q)
+        extra[f"out_m{q}"] = bazin_fitting.extract_bazin_features(df, ids)[COLUMNS["bazin"]].to_numpy(float)
+    bazin_fitting.bazin_function = real_fn
+    save("bazin", bz, nfev=nfev, **extra)
 
     # power-law block: executed from the reference script text, never copied
     src = open(os.path.join(REF, "scripts", "train_v55_powerlaw.py")).read().splitlines()
@@ -92,7 +125,18 @@ def main():
     exec(compile(block, "train_v55_powerlaw.py[106:202]", "exec"), ns)
     grouped = {k: g for k, g in df.groupby("object_id")}
     rows = [ns["extract_powerlaw_features"](i, grouped[i]) for i in ids]
-    save("powerlaw", pd.DataFrame(rows))
+    extra = {}
+    for q, d2 in enumerate(pert):
+        g2 = {k: g for k, g in d2.groupby("object_id")}
+        extra[f"out_p{q + 1}"] = pd.DataFrame([ns["extract_powerlaw_features"](i, g2[i]) for i in ids])[
+            COLUMNS["powerlaw"]].to_numpy(float)
+    real_models = dict(ns["MODELS"])
+    for q in (1, 2, 3):
+        ns["MODELS"].update({k: (noisy(fn, 200 + q), pars) for k, (fn, pars) in real_models.items()})
+        extra[f"out_m{q}"] = pd.DataFrame([ns["extract_powerlaw_features"](i, grouped[i]) for i in ids])[
+            COLUMNS["powerlaw"]].to_numpy(float)
+    ns["MODELS"].update(real_models)
+    save("powerlaw", pd.DataFrame(rows), **extra)
 
     with open(os.path.join(HERE, "columns.json"), "w") as f:
         json.dump(cols_seen, f, indent=0)

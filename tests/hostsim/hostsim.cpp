@@ -44,6 +44,8 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
                                const double* z, double* out, int32_t* status) {
     switch (set) {
         case SET_STAT: run_all<SET_STAT>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_BAZIN: run_all<SET_BAZIN>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_POWERLAW: run_all<SET_POWERLAW>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         default: return 1;
     }
 }

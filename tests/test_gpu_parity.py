@@ -110,3 +110,37 @@ def test_device_resident_path_matches_host_path():
     out, _ = db.run("stat")
     torch.cuda.synchronize()
     assert np.array_equal(np.nan_to_num(out.cpu().numpy(), nan=-7.0), np.nan_to_num(host, nan=-7.0))
+
+
+@pytest.mark.parametrize("name", ["bazin", "powerlaw"])
+def test_fits_golden(name, golden_inputs):
+    """Bounded TRF fits on the device against the real reference (stability-aware rule)."""
+    from conftest import check_fit_parity
+    got, st = extract_csr(name, golden_inputs, z=golden_inputs["z"], return_status=True)
+    check_fit_parity(got, name, COLUMNS[name])
+
+
+def test_bazin_known_answer(golden_inputs):
+    """SURVEY.md 8c known-answer fit (fixture object 260, r band)."""
+    got = extract_csr("bazin", golden_inputs)[260]
+    c = COLUMNS["bazin"]
+    want = {"r_bazin_A": 38.47790522191582, "r_bazin_t0": 59011.29707849894,
+            "r_bazin_tau_rise": 2.806862745741297, "r_bazin_tau_fall": 33.40674353526996,
+            "r_bazin_B": 0.42573133782897704, "r_bazin_fit_chi2": 1.165819932699636,
+            "r_bazin_rise_fall_ratio": 0.0840208402461331, "r_bazin_peak_flux": 38.9036365597448}
+    for k, v in want.items():
+        assert abs(got[c.index(k)] - v) <= 1e-4 * abs(v), (k, got[c.index(k)], v)
+    pl = extract_csr("powerlaw", golden_inputs)[260]
+    pc = COLUMNS["powerlaw"]
+    for k, v in {"r_powerlaw_5_3_r2": 0.6489175767591367, "r_exponential_r2": 0.9947432001615515,
+                 "r_linear_r2": 0.9038136480982363}.items():
+        assert abs(pl[pc.index(k)] - v) <= 1e-4 * abs(v), (k, pl[pc.index(k)], v)
+
+
+def test_multi_set_call_concatenates_columns(golden_inputs):
+    a = extract_csr(["stat", "bazin"], golden_inputs)
+    s = extract_csr("stat", golden_inputs)
+    b = extract_csr("bazin", golden_inputs)
+    assert a.shape[1] == 123 + 52
+    assert np.array_equal(np.nan_to_num(a[:, :123], nan=-7), np.nan_to_num(s, nan=-7))
+    assert np.array_equal(np.nan_to_num(a[:, 123:], nan=-7), np.nan_to_num(b, nan=-7))

@@ -20,3 +20,16 @@ def test_hostsim_matches_reference(name, golden_inputs):
     bad = parity.compare(got, ref, COLUMNS[name], int_cols=STAT_INT_COLUMNS if name == "stat" else (),
                          label=name, **TOL[name])
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["bazin", "powerlaw"])
+def test_hostsim_fits(name, golden_inputs):
+    from conftest import check_fit_parity
+    ncol = len(COLUMNS[name])
+    nst = {"bazin": 12, "powerlaw": 54}[name]
+    got, st = hostsim_lib.extract(SET_NAMES.index(name), golden_inputs, golden_inputs["z"], ncol=ncol, nstatus=nst)
+    check_fit_parity(got, name, COLUMNS[name])
+    # status words: a NaN block <=> status <= 0
+    if name == "bazin":
+        for k in range(6):
+            assert np.array_equal(np.isnan(got[:, 8 * k]), st[:, 2 * k] <= 0)
