@@ -4,6 +4,10 @@
 #include "stage.hpp"
 #include "stat.hpp"
 #include "fits.hpp"
+#include "tde.hpp"
+#include "color.hpp"
+#include "shape.hpp"
+#include "physics.hpp"
 
 namespace lcfe {
 
@@ -53,6 +57,27 @@ struct SetLds<SET_POWERLAW, CAP> {
     PowerlawLds<CAP> fit;
 };
 
+template <int CAP>
+struct SetLds<SET_TDE, CAP> {
+    ObjLds<CAP> obj;
+    TdeLds<CAP> s;
+};
+template <int CAP>
+struct SetLds<SET_COLOR, CAP> {
+    ObjLds<CAP> obj;
+    ColorLds<CAP> s;
+};
+template <int CAP>
+struct SetLds<SET_SHAPE, CAP> {
+    ObjLds<CAP> obj;
+    ShapeLds<CAP> s;
+};
+template <int CAP>
+struct SetLds<SET_PHYSICS, CAP> {
+    ObjLds<CAP> obj;
+    PhysicsLds<CAP> s;
+};
+
 // copy `ncol` wave-shared doubles to the object's output row (coalesced on the device)
 template <class W>
 LCFE_FN void store_row(const double* src, double* row, int ncol) {
@@ -92,6 +117,43 @@ struct RunSet<W, SET_POWERLAW, CAP> {
         stage_object<W, CAP>(in, ws.obj);
         powerlaw_object<W, CAP>(ws.obj, ws.fit, st);
         store_row<W>(ws.fit.out, row, POWERLAW_NCOL);
+        W::sync();
+    }
+};
+
+template <class W, int CAP>
+struct RunSet<W, SET_TDE, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_TDE, CAP>& ws, double* row, int32_t*) {
+        stage_object<W, CAP>(in, ws.obj);
+        tde_object<W, CAP>(ws.obj, ws.s);
+        store_row<W>(ws.s.out, row, TDE_NCOL);
+        W::sync();
+    }
+};
+template <class W, int CAP>
+struct RunSet<W, SET_COLOR, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_COLOR, CAP>& ws, double* row, int32_t*) {
+        stage_object<W, CAP>(in, ws.obj);
+        color_object<W, CAP>(ws.obj, ws.s);
+        store_row<W>(ws.s.out, row, COLOR_NCOL);
+        W::sync();
+    }
+};
+template <class W, int CAP>
+struct RunSet<W, SET_SHAPE, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_SHAPE, CAP>& ws, double* row, int32_t*) {
+        stage_object<W, CAP>(in, ws.obj);
+        shape_object<W, CAP>(ws.obj, ws.s);
+        store_row<W>(ws.s.out, row, SHAPE_NCOL);
+        W::sync();
+    }
+};
+template <class W, int CAP>
+struct RunSet<W, SET_PHYSICS, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_PHYSICS, CAP>& ws, double* row, int32_t*) {
+        stage_object<W, CAP>(in, ws.obj);
+        physics_object<W, CAP>(ws.obj, in.z, ws.s);
+        store_row<W>(ws.s.out, row, PHYSICS_NCOL);
         W::sync();
     }
 };

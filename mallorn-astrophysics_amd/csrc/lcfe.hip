@@ -143,53 +143,9 @@ int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col
     return 0;
 }
 
-const char* kStat17[] = {"n_obs", "mean", "std", "min", "max", "median", "skew", "kurtosis", "amplitude",
-                         "mad", "iqr", "beyond_1std", "beyond_2std", "max_slope", "mean_snr", "time_span",
-                         "cadence_mean"};
-const char* kBands[] = {"u", "g", "r", "i", "z", "y", "all"};
+#include "colnames.inc"
 
-std::vector<std::string> build_names(int set) {
-    std::vector<std::string> v;
-    auto B = [&](int k) { return std::string(kBands[k]); };
-    switch (set) {
-        case SET_STAT:
-            for (int k = 0; k < 7; ++k)
-                for (auto s : kStat17) v.push_back(B(k) + "_" + s);
-            v.insert(v.end(), {"flux_ratio_g_r", "flux_ratio_r_i", "flux_ratio_i_z", "peak_band"});
-            break;
-        case SET_BAZIN: {
-            const char* p8[] = {"bazin_A", "bazin_t0", "bazin_tau_rise", "bazin_tau_fall", "bazin_B",
-                                "bazin_fit_chi2", "bazin_rise_fall_ratio", "bazin_peak_flux"};
-            for (int k = 0; k < 6; ++k)
-                for (auto s : p8) v.push_back(B(k) + "_" + s);
-            v.insert(v.end(), {"bazin_rise_consistency", "bazin_fall_consistency", "bazin_avg_fit_chi2",
-                               "bazin_fit_quality_dispersion"});
-            break;
-        }
-        case SET_POWERLAW: {
-            const char* md[] = {"powerlaw_5_3", "powerlaw_1", "powerlaw_1_5", "powerlaw_2", "powerlaw_2_5",
-                                "powerlaw_3", "powerlaw_0_5", "exponential", "linear"};
-            for (int k = 1; k <= 3; ++k)
-                for (auto s : md) v.push_back(B(k) + "_" + s + "_r2");
-            break;
-        }
-        default:
-            for (int j = 0; j < set_ncols(set); ++j) v.push_back("set" + std::to_string(set) + "_" + std::to_string(j));
-    }
-    return v;
-}
-
-const std::vector<std::string>& names(int set) {
-    static std::vector<std::string> tab[NUM_SETS];
-    static bool init = false;
-    if (!init) {
-        for (int s = 0; s < NUM_SETS; ++s) tab[s] = build_names(s);
-        init = true;
-    }
-    return tab[set];
-}
-
-bool set_implemented(int set) { return set == SET_STAT || set == SET_BAZIN || set == SET_POWERLAW; }
+bool set_implemented(int set) { return set != SET_GP2D; }
 
 }  // namespace
 
@@ -232,7 +188,7 @@ const char* lcfe_colname(int mask, int64_t j) {
     if (j < 0) return nullptr;
     for (int s = 0; s < NUM_SETS; ++s) {
         if (!(mask & (1 << s))) continue;
-        if (j < set_ncols(s)) return names(s)[(size_t)j].c_str();
+        if (j < set_ncols(s)) return kColNames[s][j];
         j -= set_ncols(s);
     }
     return nullptr;
@@ -280,6 +236,10 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
             case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
             case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_TDE: rc = launch_set<SET_TDE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_COLOR: rc = launch_set<SET_COLOR>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
         }
         if (rc) return rc;
         if (prof) prof->launches[s] = nl;

@@ -46,6 +46,10 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
         case SET_STAT: run_all<SET_STAT>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_BAZIN: run_all<SET_BAZIN>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_POWERLAW: run_all<SET_POWERLAW>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_TDE: run_all<SET_TDE>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_COLOR: run_all<SET_COLOR>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_SHAPE: run_all<SET_SHAPE>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_PHYSICS: run_all<SET_PHYSICS>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         default: return 1;
     }
 }

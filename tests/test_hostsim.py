@@ -10,7 +10,8 @@ from conftest import load_golden
 from mallorn_astrophysics_amd.columns import COLUMNS, SET_NAMES, STAT_INT_COLUMNS
 
 # relative tolerance per set (floats); near-zero moments get an absolute floor
-TOL = {"stat": dict(rtol=1e-9, atol=1e-12)}
+TOL = {"stat": dict(rtol=1e-9, atol=1e-12), "tde": dict(rtol=1e-9, atol=1e-8), "color": dict(rtol=1e-9, atol=1e-10),
+       "shape": dict(rtol=1e-9, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10)}
 
 
 @pytest.mark.parametrize("name", list(TOL))
