@@ -8,6 +8,7 @@
 #include "color.hpp"
 #include "shape.hpp"
 #include "physics.hpp"
+#include "gp.hpp"
 
 namespace lcfe {
 

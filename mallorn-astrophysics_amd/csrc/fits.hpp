@@ -38,6 +38,24 @@ LCFE_FN double wave_median(const double* x, int m, double* slot) {
     return any_nan ? qnan() : med;
 }
 
+// Values of ranks lo and hi (0-based, sort order of sort_key) among n wave-shared values -> slot[0], slot[1]
+template <class W>
+LCFE_FN void wave_rank_select(const double* x, int n, int lo, int hi, double* slot) {
+    for (int i = W::lane(); i < n; i += W::LANES) {
+        const double xi = x[i];
+        const uint64_t ki = sort_key(xi);
+        int clt = 0, cle = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint64_t kj = sort_key(x[j]);
+            clt += (kj < ki);
+            cle += (kj <= ki);
+        }
+        if (clt <= lo && lo < cle) slot[0] = xi;
+        if (clt <= hi && hi < cle) slot[1] = xi;
+    }
+    W::sync();
+}
+
 // ---------------------------------------------------------------- Bazin
 struct BazinModel {
     static constexpr int NP = 5;

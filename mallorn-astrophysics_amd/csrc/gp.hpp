@@ -1,0 +1,340 @@
+// gp.hpp -- 2-D (time x wavelength) Matern-3/2 Gaussian-process features
+// (reference: src/features/multiband_gp.py; george semantics restated as in oracle/gp2d.py --
+// PARITY UNPINNED vs the real george, which is not installed anywhere in the build).
+//
+// One light curve per workgroup.  The N x N Gram matrix (N = valid points of all bands) is kept as
+// a packed lower triangle in LDS (fp64; N <= GP_CAP) and goes Gram -> Cholesky factor -> L^-1 ->
+// K^-1 in place; every L-BFGS-B evaluation needs all four (log-likelihood from L, gradient from
+// K^-1).  No MFMA: the matrices are a few hundred rows and the work is latency/LDS-bound.
+#pragma once
+#include "color.hpp"     // compute_color
+#include "fits.hpp"      // wave_median
+#include "lbfgsb.hpp"
+#include "stage.hpp"
+
+namespace lcfe {
+
+constexpr int GP_NCOL = 27;
+constexpr double GP_TINY = 1.25e-12;                        // george.gp.TINY (white noise floor)
+constexpr double GP_LOG_2PI = 1.8378770664093453;
+
+LCFE_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; }      // j <= i
+
+// Working memory of one object; NP = capacity in points.  `K` may live in LDS or in global memory.
+template <int NP>
+struct GpLds {
+    double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
+    double r[NP], z[NP], alpha[NP];           // residual y - mu, L^-1 r, K^-1 r
+    double red[8];
+    double slot[2];
+    double out[GP_NCOL + 1];
+};
+
+LCFE_FN double gp_wavelength(int band) {
+    // multiband_gp.py:26-29
+    const double w[6] = {3670.0, 4825.0, 6222.0, 7545.0, 8691.0, 9710.0};
+    return w[band];
+}
+
+// In-place packed Cholesky (right-looking, deferred scaling): on success K holds L.  Returns false
+// when a pivot is <= 0 or NaN (LAPACK dpotrf info > 0 -> george: log-likelihood = -inf).
+template <class W>
+LCFE_FN bool gp_cholesky(double* K, int n, double& logdet) {
+    const int lane = W::lane();
+    constexpr int RS = (W::LANES >= 256) ? 16 : ((W::LANES >= 64) ? 8 : 1);
+    constexpr int CS = W::LANES / RS;
+    const int ri = lane / CS, ci = lane % CS;
+    for (int j = 0; j < n; ++j) {
+        const double d2 = K[tri_index(j, j)];
+        if (!(d2 > 0.0)) return false;               // uniform: every lane reads the same word
+        const double inv = 1.0 / d2;
+        for (int i = j + 1 + ri; i < n; i += RS) {
+            const double lij = K[tri_index(i, j)] * inv;
+            const int rowi = tri_index(i, 0);
+            for (int k = j + 1 + ci; k <= i; k += CS) K[rowi + k] -= lij * K[tri_index(k, j)];
+        }
+        W::sync();
+    }
+    // scale the columns: L_ij = M_ij / sqrt(M_jj)
+    double ld = 0;
+    for (int i = lane; i < n; i += W::LANES) ld += log(K[tri_index(i, i)]);
+    logdet = W::sum(ld);                              // = sum log d2 = 2 sum log L_jj
+    for (int i = ri; i < n; i += RS) {
+        const int rowi = tri_index(i, 0);
+        for (int j = ci; j < i; j += CS) K[rowi + j] /= sqrt(K[tri_index(j, j)]);
+    }
+    W::sync();
+    for (int i = lane; i < n; i += W::LANES) K[tri_index(i, i)] = sqrt(K[tri_index(i, i)]);
+    W::sync();
+    return true;
+}
+
+// In-place inverse of the packed lower-triangular L (LAPACK dtrti2 order: last column first).
+// `col` = n doubles of scratch.
+template <class W>
+LCFE_FN void gp_tri_inverse(double* L, int n, double* col) {
+    const int lane = W::lane();
+    for (int j = n - 1; j >= 0; --j) {
+        const double ajj = 1.0 / L[tri_index(j, j)];
+        for (int i = j + 1 + lane; i < n; i += W::LANES) col[i] = L[tri_index(i, j)];
+        W::sync();
+        // x = X[j+1:, j+1:] * l_j  (X already inverted, lower triangular), then scaled by -ajj
+        for (int i = j + 1 + lane; i < n; i += W::LANES) {
+            double s = 0;
+            const int rowi = tri_index(i, 0);
+            for (int k = j + 1; k <= i; ++k) s += L[rowi + k] * col[k];
+            L[rowi + j] = -ajj * s;
+        }
+        if (lane == 0) L[tri_index(j, j)] = ajj;
+        W::sync();
+    }
+}
+
+// In place: X (lower) -> X^T X (lower part of the symmetric product), LAPACK dlauu2 order.
+template <class W>
+LCFE_FN void gp_lauum(double* X, int n, double* diag) {
+    const int lane = W::lane();
+    for (int i = lane; i < n; i += W::LANES) diag[i] = X[tri_index(i, i)];     // old diagonal (read by all)
+    W::sync();
+    for (int i = 0; i < n; ++i) {
+        const double aii = diag[i];
+        // row i, columns j < i:  X_ij <- aii*X_ij + sum_{k>i} X_kj X_ki ; diagonal: sum_{k>=i} X_ki^2
+        for (int j = lane; j <= i; j += W::LANES) {
+            double s = (j == i) ? aii * aii : aii * X[tri_index(i, j)];
+            for (int k = i + 1; k < n; ++k) s += X[tri_index(k, j)] * X[tri_index(k, i)];
+            X[tri_index(i, j)] = s;
+        }
+        W::sync();
+    }
+}
+
+struct GpParams {
+    double mu, lc, lm0, lm1;      // mean, log constant, log metric (time), log metric (wavelength)
+};
+
+// Matern-3/2 kernel value and the common derivative factor e = 1.5*c*exp(-u)
+LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1, double& e) {
+    const double u = sqrt(3.0 * (dt2 / m0 + dl2 / m1));
+    const double ex = exp(-u);
+    e = 1.5 * c * ex;
+    return c * (1.0 + u) * ex;
+}
+
+// One evaluation of f = -log-likelihood and its gradient at p (george GP.log_likelihood /
+// grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten.  On a failed
+// factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
+template <class W, int NP>
+LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& f, double g[4], bool need_grad) {
+    const int lane = W::lane();
+    const double mu = p[0], c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
+    // Gram matrix, packed lower
+    const int tot = n * (n + 1) / 2;
+    for (int i = 0; i < n; ++i) {
+        const int rowi = tri_index(i, 0);
+        for (int j = lane; j <= i; j += W::LANES) {
+            const double dt = S.t[i] - S.t[j], dl = S.lam[i] - S.lam[j];
+            double e;
+            double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
+            if (j == i) k += S.e2[i] + GP_TINY;
+            K[rowi + j] = k;
+        }
+    }
+    (void)tot;
+    for (int i = lane; i < n; i += W::LANES) S.r[i] = S.y[i] - mu;
+    W::sync();
+    double logdet;
+    g[0] = g[1] = g[2] = g[3] = 0.0;
+    if (!gp_cholesky<W>(K, n, logdet)) { f = 1e25; return; }
+    gp_tri_inverse<W>(K, n, S.z);                    // K now holds X = L^-1 (S.z used as scratch)
+    // z = X r ; alpha = X^T z ; r'K^-1 r = z'z
+    for (int i = lane; i < n; i += W::LANES) {
+        double s = 0;
+        const int rowi = tri_index(i, 0);
+        for (int k = 0; k <= i; ++k) s += K[rowi + k] * S.r[k];
+        S.z[i] = s;
+    }
+    W::sync();
+    double zz = 0, sa = 0;
+    for (int k = lane; k < n; k += W::LANES) {
+        double s = 0;
+        for (int i = k; i < n; ++i) s += K[tri_index(i, k)] * S.z[i];
+        S.alpha[k] = s;
+        sa += s;
+        zz += S.z[k] * S.z[k];
+    }
+    zz = W::sum(zz);
+    sa = W::sum(sa);
+    const double ll = -0.5 * (zz + logdet + n * GP_LOG_2PI);
+    f = finite_d(ll) ? -ll : 1e25;
+    W::sync();
+    if (!need_grad) return;
+    gp_lauum<W>(K, n, S.z);                          // K now holds K^-1 (lower); z is free again
+    // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta
+    double g1 = 0, g2 = 0, g3 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rowi = tri_index(i, 0);
+        const double ai = S.alpha[i];
+        for (int j = lane; j <= i; j += W::LANES) {
+            const double dt = S.t[i] - S.t[j], dl = S.lam[i] - S.lam[j];
+            const double dt2 = dt * dt, dl2 = dl * dl;
+            double e;
+            const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
+            const double a = (ai * S.alpha[j] - K[rowi + j]) * ((j == i) ? 1.0 : 2.0);
+            g1 += a * k;
+            g2 += a * e * dt2 / m0;
+            g3 += a * e * dl2 / m1;
+        }
+    }
+    g1 = W::sum(g1);
+    g2 = W::sum(g2);
+    g3 = W::sum(g3);
+    // objective is the NEGATIVE log-likelihood
+    g[0] = -sa;
+    g[1] = -0.5 * g1;
+    g[2] = -0.5 * g2;
+    g[3] = -0.5 * g3;
+    W::sync();
+}
+
+LCFE_FN bool gp_row_valid(const ObjIn& in, int i) {
+    // multiband_gp.py:51-59: known band, flux and error not NaN, error > 0
+    const double f = in.f[i], e = in.e[i];
+    return (in.b[i] < 6) && !is_nan(f) && !is_nan(e) && (e > 0);
+}
+
+// multiband_gp.py:292-344 for one object (rows read straight from the CSR slice, file order).
+// `K` points to packed-triangle storage for NP points (LDS or global scratch).
+template <class W, int NP>
+LCFE_FN void gp_object(const ObjIn& L, GpLds<NP>& S, double* K, int32_t* st) {
+    const int lane = W::lane();
+    double* o = S.out;
+    for (int k = lane; k < GP_NCOL; k += W::LANES) o[k] = qnan();
+    // ---- prepare_multiband_data (:34-87): valid rows in file order
+    int n = 0;
+    double tmin_all = __builtin_inf();
+    for (int i = lane; i < L.n; i += W::LANES) {
+        tmin_all = fmin(tmin_all, L.t[i]);
+        n += gp_row_valid(L, i) ? 1 : 0;
+    }
+    n = W::sum(n);
+    if (n >= 10 && n <= NP) {
+        for (int i = lane; i < L.n; i += W::LANES) {
+            if (!gp_row_valid(L, i)) continue;
+            int pos = 0;
+            for (int j = 0; j < i; ++j) pos += gp_row_valid(L, j) ? 1 : 0;
+            S.t[pos] = L.t[i];
+            S.lam[pos] = gp_wavelength(L.b[i]);
+            S.y[pos] = L.f[i];
+            S.e2[pos] = L.e[i];
+        }
+    }
+    tmin_all = W::min(tmin_all);
+    W::sync();
+    if (st && lane == 0) { st[0] = 0; st[1] = 0; st[2] = 0; st[3] = n; }
+    if (n < 10) { W::sync(); return; }                                  // :66 -> all 27 NaN
+    if (n > NP) { if (st && lane == 0) st[0] = -100; W::sync(); return; }
+    double tmin = __builtin_inf();
+    int nnz = 0;
+    for (int i = lane; i < n; i += W::LANES) { tmin = fmin(tmin, S.t[i]); }
+    tmin = W::min(tmin);
+    // flux_scale = median(|f| over f != 0) (:78-80): zeros are parked at +inf so that the non-zero
+    // values occupy ranks 0..nnz-1 (r[] is scratch here)
+    for (int i = lane; i < n; i += W::LANES) {
+        const bool nz = (S.y[i] != 0.0);
+        S.r[i] = nz ? fabs(S.y[i]) : __builtin_inf();
+        nnz += nz ? 1 : 0;
+    }
+    nnz = W::sum(nnz);
+    W::sync();
+    double scale = qnan();
+    if (nnz > 0) {
+        wave_rank_select<W>(S.r, n, (nnz - 1) / 2, nnz / 2, S.slot);
+        scale = ((nnz & 1) ? S.slot[0] : (S.slot[0] + S.slot[1]) / 2.0);
+        W::sync();
+    }
+    if (scale == 0) scale = 1.0;
+    double sy = 0;
+    for (int i = lane; i < n; i += W::LANES) {
+        S.t[i] -= tmin;                                                 // :75
+        S.y[i] /= scale;                                                // :81-82
+        const double e = S.e2[i] / scale;
+        S.e2[i] = e * e;
+        sy += S.y[i];
+    }
+    W::sync();
+    const double ymean = W::sum(sy) / n;
+    double sv = 0;
+    for (int i = lane; i < n; i += W::LANES) { const double d = S.y[i] - ymean; sv += d * d; }
+    const double yvar = W::sum(sv) / n;                                 // :125 np.var
+    // ---- fit_multiband_gp (:90-193)
+    double p[4] = {ymean, log(yvar / 2.0), log(100.0 * 100.0), log(6000.0 * 6000.0)};   // amp/ndim: george `float * kernel`
+    bool finite0 = finite_d(p[0]) && finite_d(p[1]);
+    double fval = 0;
+    int n_iter = 0, n_eval = 0, why = LB_ERROR;
+    if (finite0) {
+        auto ev = [&](const double* x, double& f, double* g) { gp_eval<W, NP>(x, n, S, K, f, g, true); };
+        why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval);
+    }
+    if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
+    if (!finite0 || !(finite_d(p[0]) && finite_d(p[1]) && finite_d(p[2]) && finite_d(p[3]))) { W::sync(); return; }
+    // features read params[0..2] of george's vector [mean, log_constant, log_M_0_0, log_M_1_1] (:171-188)
+    const double amplitude = exp(p[0]);
+    const double ts = sqrt(exp(p[1]));
+    const double ws = sqrt(exp(p[2]));
+    if (lane == 0) {
+        o[0] = amplitude; o[1] = ts; o[2] = ws; o[3] = -fval; o[4] = ts / (ws / 1000);
+    }
+    // ---- peak time (:331-338): first max of the r rows (file order; pandas idxmax skips NaN), else of all rows
+    int pk = -1;
+    const ObjIn& Lr = L;
+    (void)Lr;
+    {
+        double best = -__builtin_inf();
+        int nr = 0;
+        for (int i = lane; i < L.n; i += W::LANES) nr += (L.b[i] == 2);
+        nr = W::sum(nr);
+        const bool use_r = nr > 0;
+        for (int i = lane; i < L.n; i += W::LANES)
+            if ((!use_r || L.b[i] == 2) && !is_nan(L.f[i])) best = fmax(best, L.f[i]);
+        best = W::max(best);
+        int cand = 0x7fffffff;
+        for (int i = lane; i < L.n; i += W::LANES)
+            if ((!use_r || L.b[i] == 2) && L.f[i] == best) cand = (i < cand) ? i : cand;
+        pk = W::min(cand);
+    }
+    if (pk == 0x7fffffff) { W::sync(); return; }
+    const double peak_time = L.t[pk] - tmin_all;
+    // ---- interpolate_multiband (:196-289): alpha at the optimum, then 12 predictions
+    double ftmp, gtmp[4];
+    gp_eval<W, NP>(p, n, S, K, ftmp, gtmp, false);
+    if (ftmp >= 1e25) { W::sync(); return; }          // factorisation failed at the optimum: predict raises -> NaN (:279-287)
+    const double c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
+    const double EP[4] = {0, 20, 50, 100};
+    const int PB[3] = {1, 2, 3};
+    double fl[12];
+    for (int q = 0; q < 12; ++q) {
+        const double tp = peak_time + EP[q / 3], lp = gp_wavelength(PB[q % 3]);
+        double s = 0;
+        for (int i = lane; i < n; i += W::LANES) {
+            const double dt = tp - S.t[i], dl = lp - S.lam[i];
+            double e;
+            s += gp_kernel(dt * dt, dl * dl, c, m0, m1, e) * S.alpha[i];
+        }
+        fl[q] = (p[0] + W::sum(s)) * scale;                              // :244-247
+    }
+    if (lane == 0) {
+        double gr[4];
+        for (int e = 0; e < 4; ++e) {
+            const double gf = fl[3 * e], rf = fl[3 * e + 1], iff = fl[3 * e + 2];
+            o[5 + 5 * e] = gf; o[6 + 5 * e] = rf; o[7 + 5 * e] = iff;
+            gr[e] = (gf > 0 && rf > 0) ? -2.5 * log10(gf / rf) : qnan();             // :254-262
+            o[8 + 5 * e] = gr[e];
+            o[9 + 5 * e] = (rf > 0 && iff > 0) ? -2.5 * log10(rf / iff) : qnan();
+        }
+        o[25] = (!is_nan(gr[0]) && !is_nan(gr[2])) ? (gr[2] - gr[0]) / 50.0 : qnan();   // :265-277
+        o[26] = (!is_nan(gr[0]) && !is_nan(gr[3])) ? (gr[3] - gr[0]) / 100.0 : qnan();
+    }
+    W::sync();
+}
+
+}  // namespace lcfe

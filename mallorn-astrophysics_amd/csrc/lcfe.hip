@@ -77,6 +77,80 @@ __global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_t
     }
 }
 
+int num_cus(int dev);
+
+// ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 190) or,
+// for longer light curves, in a per-workgroup slab of global scratch.
+constexpr int kGpGlobalNP = 1024;
+constexpr int kGpGlobalGrid = 256;
+
+template <int NP, bool GLOBAL_K>
+__global__ __launch_bounds__(256) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
+                                                 int col0, int32_t* status, int st_ld, int st0, double* kscratch) {
+    using W = BlockDev<256>;
+    __shared__ GpLds<NP> S;
+    __shared__ double Klds[GLOBAL_K ? 1 : NP * (NP + 1) / 2];
+    double* K = GLOBAL_K ? kscratch + (size_t)blockIdx.x * ((size_t)NP * (NP + 1) / 2) : Klds;
+    for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
+        const int64_t s = B.offsets[i];
+        const int64_t n64 = B.offsets[i + 1] - s;
+        if (n64 <= lo) continue;
+        double* row = out + i * (int64_t)ld + col0;
+        int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
+        if (n64 > hi) {
+            if (last_tier) {
+                fill_row_nan<W>(row, GP_NCOL);
+                if (st && threadIdx.x < 4) st[threadIdx.x] = -100;
+            }
+            continue;
+        }
+        ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
+        gp_object<W, NP>(in, S, K, st);
+        store_row<W>(S.out, row, GP_NCOL);
+        __syncthreads();
+    }
+}
+
+template <int NP, bool GLOBAL_K>
+int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
+                   int st_ld, int st0, hipStream_t stream, int dev, double* kscratch) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, 256, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (GLOBAL_K && grid > kGpGlobalGrid) grid = kGpGlobalGrid;
+    if (grid > B.n_obj) grid = B.n_obj;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(256), 0, stream, B, lo, hi, last, out, ld,
+                       col0, status, st_ld, st0, kscratch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
+              int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch) {
+    const int caps[4] = {64, 128, 190, kGpGlobalNP};
+    int last = 0;
+    while (last < 3 && caps[last] < max_len) ++last;
+    if (last == 3 && kscratch_bytes < (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8)
+        return fail_msg("lcfe_extract_device: workspace too small for the GP global tier");
+    int lo = -1;
+    for (int ti = 0; ti <= last; ++ti) {
+        const int is_last = (ti == last);
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_gp_tier<64, false>(B, lo, 64, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 1: rc = launch_gp_tier<128, false>(B, lo, 128, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 2: rc = launch_gp_tier<190, false>(B, lo, 190, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, kGpGlobalNP, is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+        lo = caps[ti];
+    }
+    return 0;
+}
+
 struct Tier { int cap; };
 const int kTiers[] = {128, 256, 512, 1024, 2048};
 constexpr int kNumTiers = 5;
@@ -145,7 +219,7 @@ int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col
 
 #include "colnames.inc"
 
-bool set_implemented(int set) { return set != SET_GP2D; }
+bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
 
 }  // namespace
 
@@ -194,14 +268,16 @@ const char* lcfe_colname(int mask, int64_t j) {
     return nullptr;
 }
 
-size_t lcfe_workspace_bytes(int, int64_t, int64_t) { return 256; }
+size_t lcfe_workspace_bytes(int mask, int64_t, int64_t) {
+    size_t b = 256;
+    if (mask & (1 << SET_GP2D)) b += (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8;
+    return b;
+}
 
 int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int64_t n_points,
                         int64_t max_len, const int64_t* d_offsets, const double* d_t, const double* d_flux,
                         const double* d_err, const uint8_t* d_band, const double* d_z, double* d_out,
                         int32_t* d_status, void* d_workspace, size_t workspace_bytes, lcfe_stats* prof) {
-    (void)d_workspace;
-    (void)workspace_bytes;
     g_err.clear();
     if (mask <= 0 || mask > LCFE_MASK_ALL) return fail_msg("lcfe_extract_device: empty or unknown feature-set mask");
     for (int s = 0; s < NUM_SETS; ++s)
@@ -240,6 +316,10 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_COLOR: rc = launch_set<SET_COLOR>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
             case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
             case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_GP2D:
+                rc = launch_gp(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, (double*)d_workspace,
+                               d_workspace ? workspace_bytes : 0, &nl);
+                break;
         }
         if (rc) return rc;
         if (prof) prof->launches[s] = nl;

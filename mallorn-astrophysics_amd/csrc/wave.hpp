@@ -74,6 +74,39 @@ struct WaveDev {
 };
 #endif
 
+#if defined(__HIPCC__)
+// A workgroup of T threads (T/64 wavefronts) working on one object: the GP kernel's policy.
+// Reductions go through the wave shuffle network and a small LDS exchange (two barriers each).
+template <int T>
+struct BlockDev {
+    static constexpr int LANES = T;
+    static constexpr int NW = T / 64;
+    static __device__ __forceinline__ int lane() { return threadIdx.x; }
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class V, class Op>
+    static __device__ __forceinline__ V reduce(V v, Op op) {
+        __shared__ V part[NW];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        V r = part[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) r = op(r, part[k]);
+        __syncthreads();
+        return r;
+    }
+    static __device__ __forceinline__ double sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+    static __device__ __forceinline__ double max(double v) { return reduce(v, [](double a, double b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ double min(double v) { return reduce(v, [](double a, double b) { return (b < a) ? b : a; }); }
+    static __device__ __forceinline__ int sum(int v) { return reduce(v, [](int a, int b) { return a + b; }); }
+    static __device__ __forceinline__ int max(int v) { return reduce(v, [](int a, int b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ int min(int v) { return reduce(v, [](int a, int b) { return (b < a) ? b : a; }); }
+    static __device__ __forceinline__ bool any(bool p) { return sum(p ? 1 : 0) != 0; }
+    static __device__ __forceinline__ bool all(bool p) { return sum(p ? 0 : 1) == 0; }
+};
+#endif
+
 struct WaveHost {
     static constexpr int LANES = 1;
     static int lane() { return 0; }

@@ -33,10 +33,11 @@ def load_golden_fit(name):
     return g["out"], [g[k] for k in ("out_p1", "out_p2", "out_m1", "out_m2", "out_m3")]
 
 
-def check_fit_parity(got, name, cols, max_stable_bad=2):
+def check_fit_parity(got, name, cols, max_stable_bad=2, ref=None, probes=None):
     """Parity rule of the bounded fits (DESIGN.md "Parity of the bounded fits")."""
     import parity
-    ref, probes = load_golden_fit(name)
+    if ref is None:
+        ref, probes = load_golden_fit(name)
     bad, summ = parity.compare_fits(got, ref, probes, name, cols, rtol=1e-4)
     print(name, summ)
     # (1) fits the reference reproduces under one-ulp probes must match to 1e-4 (a handful of
@@ -48,3 +49,9 @@ def check_fit_parity(got, name, cols, max_stable_bad=2):
     # (3) NaN mask: only chaotic fits (max_nfev / infeasible after a long walk) may differ
     assert summ["nan_mask_mismatches"] <= 0.01 * summ["n_fits"], summ
     return summ
+
+
+def load_gp_oracle_fixture():
+    """ORACLE outputs (parity unpinned: george absent) + two one-ulp probe runs."""
+    g = np.load(os.path.join(GOLDEN, "golden_gp2d_oracle.npz"))
+    return g["out"], [g["out_p1"], g["out_p2"]]

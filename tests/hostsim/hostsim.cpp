@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "../../mallorn-astrophysics_amd/csrc/feature_sets.hpp"
 
@@ -39,6 +40,21 @@ static void run_all(int64_t n_obj, const int64_t* offsets, const double* t, cons
     }
 }
 
+// the GP kernel has its own working set (Gram matrix) and reads the CSR slice directly
+static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux, const double* err,
+                   const uint8_t* band, double* out, int32_t* status) {
+    using W = WaveHost;
+    constexpr int NP = 1024;
+    auto ws = std::make_unique<GpLds<NP>>();
+    std::vector<double> K((size_t)NP * (NP + 1) / 2);
+    for (int64_t i = 0; i < n_obj; ++i) {
+        const int64_t s = offsets[i];
+        ObjIn in{t + s, flux + s, err + s, band + s, (int)(offsets[i + 1] - s), qnan()};
+        gp_object<W, NP>(in, *ws, K.data(), status ? status + 4 * i : nullptr);
+        for (int k = 0; k < GP_NCOL; ++k) out[i * GP_NCOL + k] = ws->out[k];
+    }
+}
+
 extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, const double* t,
                                const double* flux, const double* err, const uint8_t* band,
                                const double* z, double* out, int32_t* status) {
@@ -50,6 +66,7 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
         case SET_COLOR: run_all<SET_COLOR>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_SHAPE: run_all<SET_SHAPE>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_PHYSICS: run_all<SET_PHYSICS>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_GP2D: run_gp(n_obj, offsets, t, flux, err, band, out, status); return 0;
         default: return 1;
     }
 }

@@ -44,6 +44,8 @@ def fit_blocks(name):
         return [(8 * k, 8 * k + 8) for k in range(6)]
     if name == "powerlaw":
         return [(j, j + 1) for j in range(27)]
+    if name == "gp2d":
+        return [(0, 27)]
     raise KeyError(name)
 
 

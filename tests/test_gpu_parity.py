@@ -169,3 +169,30 @@ def test_dataframe_boundary_all_extractors(golden_inputs):
     assert list(bz.columns) == COLUMNS["bazin"] + ["object_id"]
     pw = powerlaw.extract_powerlaw_features(df, want)
     assert list(pw.columns) == ["object_id"] + COLUMNS["powerlaw"]
+
+
+def test_gp2d_vs_oracle(golden_inputs):
+    """2-D GP on the device vs the scipy-driven oracle.  PARITY UNPINNED: the reference uses george,
+    which is absent; the oracle restates george's published algorithm (oracle/gp2d.py)."""
+    from conftest import check_fit_parity, load_gp_oracle_fixture
+    ref, probes = load_gp_oracle_fixture()
+    got, st = extract_csr("gp2d", golden_inputs, return_status=True)
+    check_fit_parity(got, "gp2d", COLUMNS["gp2d"], ref=ref, probes=probes, max_stable_bad=3)
+    assert (st[:, 3] == np.array([((golden_inputs["band"][a:b] < 6) & ~np.isnan(golden_inputs["flux"][a:b])
+                                   & ~np.isnan(golden_inputs["err"][a:b]) & (golden_inputs["err"][a:b] > 0)).sum()
+                                  for a, b in zip(golden_inputs["offsets"][:-1], golden_inputs["offsets"][1:])])).all()
+
+
+def test_gp2d_long_objects_use_global_tier():
+    rng = np.random.default_rng(3)
+    objs = []
+    for n in (60, 130, 191, 400):
+        t = np.sort(59000 + rng.uniform(0, 300, n))
+        b = rng.choice(6, n)
+        f = 30 * np.exp(-0.5 * ((t - 59100) / 30) ** 2) * (1 + 0.1 * b) + rng.normal(0, 1, n)
+        objs.append((t, f, np.full(n, 1.0), b))
+    lc = synth.from_objects(objs)
+    got = extract_csr("gp2d", lc)
+    ref = oracle.extract("gp2d", lc)
+    bad = parity.compare(got, ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
+    assert len(bad) <= 2, "\n".join(bad)
