@@ -20,12 +20,18 @@ constexpr double GP_LOG_2PI = 1.8378770664093453;
 
 LCFE_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; }      // j <= i
 
-// Working memory of one object; NP = capacity in points.  `K` may live in LDS or in global memory.
+constexpr int GP_B = 8;                                      // pivot-block width of the sweep
+
+// Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
+// doubles) lives in LDS for the small tiers and in a per-workgroup slab of global scratch otherwise.
 template <int NP>
 struct GpLds {
     double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
-    double r[NP], z[NP], alpha[NP];           // residual y - mu, L^-1 r, K^-1 r
-    double red[8];
+    double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
+    double V[GP_B][NP];                       // pivot-block columns A(:, P)
+    double Wm[GP_B][NP];                      // A(:, P) * A(P,P)^-1
+    double P[GP_B][GP_B];                     // pivot block -> its inverse
+    double lb_s[10][4], lb_y[10][4], lb_rho[10];   // L-BFGS memory (block-uniform, kept out of registers)
     double slot[2];
     double out[GP_NCOL + 1];
 };
@@ -36,81 +42,88 @@ LCFE_FN double gp_wavelength(int band) {
     return w[band];
 }
 
-// In-place packed Cholesky (right-looking, deferred scaling): on success K holds L.  Returns false
-// when a pivot is <= 0 or NaN (LAPACK dpotrf info > 0 -> george: log-likelihood = -inf).
-template <class W>
-LCFE_FN bool gp_cholesky(double* K, int n, double& logdet) {
+// In-place inverse of the packed symmetric positive-definite matrix A (lower triangle, row-major)
+// by a BLOCKED SYMMETRIC SWEEP: for each pivot block P of GP_B consecutive indices
+//     A_PP <- -A_PP^-1 ,  A_RP <- A_RP A_PP^-1 ,  A_RR <- A_RR - A_RP A_PP^-1 A_PR     (R = all other indices)
+// After all blocks A = -K^-1.  The pivots met while inverting the diagonal blocks are exactly the
+// Cholesky pivots L_jj^2, so log|K| = sum log(pivot) and "pivot <= 0" is LAPACK dpotrf's failure
+// (george: log-likelihood = -inf).  n/GP_B block steps, each a fully parallel rank-GP_B update of
+// the whole triangle -- this is what replaces the n sequential columns of a textbook Cholesky.
+template <class W, int NP>
+LCFE_FN bool gp_sweep_inverse(double* A, int n, GpLds<NP>& S, double& logdet) {
     const int lane = W::lane();
-    constexpr int RS = (W::LANES >= 256) ? 16 : ((W::LANES >= 64) ? 8 : 1);
-    constexpr int CS = W::LANES / RS;
-    const int ri = lane / CS, ci = lane % CS;
-    for (int j = 0; j < n; ++j) {
-        const double d2 = K[tri_index(j, j)];
-        if (!(d2 > 0.0)) return false;               // uniform: every lane reads the same word
-        const double inv = 1.0 / d2;
-        for (int i = j + 1 + ri; i < n; i += RS) {
-            const double lij = K[tri_index(i, j)] * inv;
+    constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;     // lanes that share one matrix row
+    constexpr int RG = W::LANES / G;                        // rows in flight
+    const int rl = lane / G, cl = lane % G;
+    double ld = 0.0;
+    for (int k0 = 0; k0 < n; k0 += GP_B) {
+        const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
+        // (1) V[p][i] = A(i, k0+p) for every i (symmetric access)
+        for (int p = 0; p < bs; ++p) {
+            const int kp = k0 + p;
+            for (int i = lane; i < n; i += W::LANES) S.V[p][i] = (i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)];
+        }
+        W::sync();
+        // (2) P <- A_PP^-1 by an unblocked sweep of the bs x bs block (sign-flipped at the end)
+        for (int e = lane; e < bs * bs; e += W::LANES) S.P[e / bs][e % bs] = S.V[e % bs][k0 + e / bs];
+        W::sync();
+        for (int q = 0; q < bs; ++q) {
+            const double d = S.P[q][q];
+            if (!(d > 0.0)) return false;                   // uniform
+            ld += log(d);
+            constexpr int NV = (GP_B * GP_B + W::LANES - 1) / W::LANES;
+            double nv[NV];
+            int cnt = 0;
+            for (int e = lane; e < bs * bs; e += W::LANES) {
+                const int a = e / bs, b = e % bs;
+                double v;
+                if (a == q && b == q) v = -1.0 / d;
+                else if (a == q) v = S.P[q][b] / d;
+                else if (b == q) v = S.P[a][q] / d;
+                else v = S.P[a][b] - S.P[a][q] * S.P[q][b] / d;
+                nv[cnt++] = v;
+            }
+            W::sync();
+            cnt = 0;
+            for (int e = lane; e < bs * bs; e += W::LANES) S.P[e / bs][e % bs] = nv[cnt++];
+            W::sync();
+        }
+        // now S.P = -A_PP^-1
+        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -S.P)
+        for (int p = 0; p < bs; ++p)
+            for (int i = lane; i < n; i += W::LANES) {
+                double s = 0;
+                for (int q = 0; q < bs; ++q) s -= S.V[q][i] * S.P[q][p];
+                S.Wm[p][i] = s;
+            }
+        W::sync();
+        // (4) rank-bs update of the whole triangle + the new pivot columns
+        for (int i = rl; i < n; i += RG) {
             const int rowi = tri_index(i, 0);
-            for (int k = j + 1 + ci; k <= i; k += CS) K[rowi + k] -= lij * K[tri_index(k, j)];
+            const bool i_in = (i >= k0 && i < k0 + bs);
+            double wi[GP_B];
+#pragma unroll
+            for (int p = 0; p < GP_B; ++p) wi[p] = (p < bs) ? S.Wm[p][i] : 0.0;
+            for (int j = cl; j <= i; j += G) {
+                const bool j_in = (j >= k0 && j < k0 + bs);
+                double v;
+                if (i_in && j_in) v = S.P[i - k0][j - k0];                      // -A_PP^-1
+                else if (j_in) v = S.Wm[j - k0][i];                             // A_RP A_PP^-1 (row i below/after the block)
+                else if (i_in) v = S.Wm[i - k0][j];                             // (row i in the block, column j before it)
+                else {
+                    double acc = 0;
+#pragma unroll
+                    for (int p = 0; p < GP_B; ++p) acc += wi[p] * ((p < bs) ? S.V[p][j] : 0.0);
+                    v = A[rowi + j] - acc;
+                }
+                A[rowi + j] = v;
+            }
         }
         W::sync();
     }
-    // scale the columns: L_ij = M_ij / sqrt(M_jj)
-    double ld = 0;
-    for (int i = lane; i < n; i += W::LANES) ld += log(K[tri_index(i, i)]);
-    logdet = W::sum(ld);                              // = sum log d2 = 2 sum log L_jj
-    for (int i = ri; i < n; i += RS) {
-        const int rowi = tri_index(i, 0);
-        for (int j = ci; j < i; j += CS) K[rowi + j] /= sqrt(K[tri_index(j, j)]);
-    }
-    W::sync();
-    for (int i = lane; i < n; i += W::LANES) K[tri_index(i, i)] = sqrt(K[tri_index(i, i)]);
-    W::sync();
+    logdet = ld;
     return true;
 }
-
-// In-place inverse of the packed lower-triangular L (LAPACK dtrti2 order: last column first).
-// `col` = n doubles of scratch.
-template <class W>
-LCFE_FN void gp_tri_inverse(double* L, int n, double* col) {
-    const int lane = W::lane();
-    for (int j = n - 1; j >= 0; --j) {
-        const double ajj = 1.0 / L[tri_index(j, j)];
-        for (int i = j + 1 + lane; i < n; i += W::LANES) col[i] = L[tri_index(i, j)];
-        W::sync();
-        // x = X[j+1:, j+1:] * l_j  (X already inverted, lower triangular), then scaled by -ajj
-        for (int i = j + 1 + lane; i < n; i += W::LANES) {
-            double s = 0;
-            const int rowi = tri_index(i, 0);
-            for (int k = j + 1; k <= i; ++k) s += L[rowi + k] * col[k];
-            L[rowi + j] = -ajj * s;
-        }
-        if (lane == 0) L[tri_index(j, j)] = ajj;
-        W::sync();
-    }
-}
-
-// In place: X (lower) -> X^T X (lower part of the symmetric product), LAPACK dlauu2 order.
-template <class W>
-LCFE_FN void gp_lauum(double* X, int n, double* diag) {
-    const int lane = W::lane();
-    for (int i = lane; i < n; i += W::LANES) diag[i] = X[tri_index(i, i)];     // old diagonal (read by all)
-    W::sync();
-    for (int i = 0; i < n; ++i) {
-        const double aii = diag[i];
-        // row i, columns j < i:  X_ij <- aii*X_ij + sum_{k>i} X_kj X_ki ; diagonal: sum_{k>=i} X_ki^2
-        for (int j = lane; j <= i; j += W::LANES) {
-            double s = (j == i) ? aii * aii : aii * X[tri_index(i, j)];
-            for (int k = i + 1; k < n; ++k) s += X[tri_index(k, j)] * X[tri_index(k, i)];
-            X[tri_index(i, j)] = s;
-        }
-        W::sync();
-    }
-}
-
-struct GpParams {
-    double mu, lc, lm0, lm1;      // mean, log constant, log metric (time), log metric (wavelength)
-};
 
 // Matern-3/2 kernel value and the common derivative factor e = 1.5*c*exp(-u)
 LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1, double& e) {
@@ -121,65 +134,61 @@ LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1,
 }
 
 // One evaluation of f = -log-likelihood and its gradient at p (george GP.log_likelihood /
-// grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten.  On a failed
-// factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
+// grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten (by -K^-1).  On a
+// failed factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
 template <class W, int NP>
 LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& f, double g[4], bool need_grad) {
     const int lane = W::lane();
+    constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;
+    constexpr int RG = W::LANES / G;
+    const int rl = lane / G, cl = lane % G;
     const double mu = p[0], c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
     // Gram matrix, packed lower
-    const int tot = n * (n + 1) / 2;
-    for (int i = 0; i < n; ++i) {
+    for (int i = rl; i < n; i += RG) {
         const int rowi = tri_index(i, 0);
-        for (int j = lane; j <= i; j += W::LANES) {
-            const double dt = S.t[i] - S.t[j], dl = S.lam[i] - S.lam[j];
+        const double ti = S.t[i], li = S.lam[i];
+        for (int j = cl; j <= i; j += G) {
+            const double dt = ti - S.t[j], dl = li - S.lam[j];
             double e;
             double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
             if (j == i) k += S.e2[i] + GP_TINY;
             K[rowi + j] = k;
         }
     }
-    (void)tot;
     for (int i = lane; i < n; i += W::LANES) S.r[i] = S.y[i] - mu;
     W::sync();
     double logdet;
     g[0] = g[1] = g[2] = g[3] = 0.0;
-    if (!gp_cholesky<W>(K, n, logdet)) { f = 1e25; return; }
-    gp_tri_inverse<W>(K, n, S.z);                    // K now holds X = L^-1 (S.z used as scratch)
-    // z = X r ; alpha = X^T z ; r'K^-1 r = z'z
+    if (!gp_sweep_inverse<W, NP>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
+    // alpha = K^-1 r = -(A r) with A symmetric packed ; r' K^-1 r = r . alpha
+    double ra = 0, sa = 0;
     for (int i = lane; i < n; i += W::LANES) {
         double s = 0;
         const int rowi = tri_index(i, 0);
         for (int k = 0; k <= i; ++k) s += K[rowi + k] * S.r[k];
-        S.z[i] = s;
-    }
-    W::sync();
-    double zz = 0, sa = 0;
-    for (int k = lane; k < n; k += W::LANES) {
-        double s = 0;
-        for (int i = k; i < n; ++i) s += K[tri_index(i, k)] * S.z[i];
-        S.alpha[k] = s;
+        for (int k = i + 1; k < n; ++k) s += K[tri_index(k, i)] * S.r[k];
+        s = -s;
+        S.alpha[i] = s;
         sa += s;
-        zz += S.z[k] * S.z[k];
+        ra += S.r[i] * s;
     }
-    zz = W::sum(zz);
+    ra = W::sum(ra);
     sa = W::sum(sa);
-    const double ll = -0.5 * (zz + logdet + n * GP_LOG_2PI);
+    const double ll = -0.5 * (ra + logdet + n * GP_LOG_2PI);
     f = finite_d(ll) ? -ll : 1e25;
     W::sync();
     if (!need_grad) return;
-    gp_lauum<W>(K, n, S.z);                          // K now holds K^-1 (lower); z is free again
-    // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta
+    // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta ,  Kinv_ij = -K[ij]
     double g1 = 0, g2 = 0, g3 = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = rl; i < n; i += RG) {
         const int rowi = tri_index(i, 0);
-        const double ai = S.alpha[i];
-        for (int j = lane; j <= i; j += W::LANES) {
-            const double dt = S.t[i] - S.t[j], dl = S.lam[i] - S.lam[j];
+        const double ai = S.alpha[i], ti = S.t[i], li = S.lam[i];
+        for (int j = cl; j <= i; j += G) {
+            const double dt = ti - S.t[j], dl = li - S.lam[j];
             const double dt2 = dt * dt, dl2 = dl * dl;
             double e;
             const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
-            const double a = (ai * S.alpha[j] - K[rowi + j]) * ((j == i) ? 1.0 : 2.0);
+            const double a = (ai * S.alpha[j] + K[rowi + j]) * ((j == i) ? 1.0 : 2.0);
             g1 += a * k;
             g2 += a * e * dt2 / m0;
             g3 += a * e * dl2 / m1;
@@ -273,7 +282,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP>& S, double* K, int32_t* st) {
     int n_iter = 0, n_eval = 0, why = LB_ERROR;
     if (finite0) {
         auto ev = [&](const double* x, double& f, double* g) { gp_eval<W, NP>(x, n, S, K, f, g, true); };
-        why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval);
+        why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval, S.lb_s, S.lb_y, S.lb_rho);
     }
     if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
     if (!finite0 || !(finite_d(p[0]) && finite_d(p[1]) && finite_d(p[2]) && finite_d(p[3]))) { W::sync(); return; }

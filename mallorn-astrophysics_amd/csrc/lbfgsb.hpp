@@ -178,9 +178,10 @@ enum { LB_CONVERGED_PG = 1, LB_CONVERGED_F = 2, LB_MAXITER = 3, LB_ABNORMAL = 4,
 // must return uniform results.  Returns the stop reason; x, f hold the final iterate.
 template <int N, int M, class Eval>
 LCFE_FN int lbfgsb_minimize(double x[N], double& f, Eval&& eval, int maxiter, double factr, double pgtol,
-                            int maxls, int& n_iter, int& n_eval) {
+                            int maxls, int& n_iter, int& n_eval, double (*Sm)[N], double (*Ym)[N], double* rho) {
+    // Sm, Ym, rho: circular memory of the (s, y) pairs -- M rows of caller-provided (wave-shared)
+    // storage; every lane writes the same values, so no fence is needed between lanes.
     double g[N], d[N], t[N], r[N];
-    double Sm[M][N], Ym[M][N], rho[M];     // circular memory of (s, y) pairs
     int col = 0, head = 0;
     double theta = 1.0;
     n_iter = 0;

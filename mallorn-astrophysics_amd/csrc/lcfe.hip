@@ -79,9 +79,9 @@ __global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_t
 
 int num_cus(int dev);
 
-// ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 190) or,
+// ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 176) or,
 // for longer light curves, in a per-workgroup slab of global scratch.
-constexpr int kGpGlobalNP = 1024;
+constexpr int kGpGlobalNP = 768;
 constexpr int kGpGlobalGrid = 256;
 
 template <int NP, bool GLOBAL_K>
@@ -129,7 +129,7 @@ int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, in
 
 int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
               int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch) {
-    const int caps[4] = {64, 128, 190, kGpGlobalNP};
+    const int caps[4] = {64, 120, 176, kGpGlobalNP};
     int last = 0;
     while (last < 3 && caps[last] < max_len) ++last;
     if (last == 3 && kscratch_bytes < (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8)
@@ -140,8 +140,8 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
         int rc = 0;
         switch (ti) {
             case 0: rc = launch_gp_tier<64, false>(B, lo, 64, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 1: rc = launch_gp_tier<128, false>(B, lo, 128, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 2: rc = launch_gp_tier<190, false>(B, lo, 190, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 1: rc = launch_gp_tier<120, false>(B, lo, 120, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 2: rc = launch_gp_tier<176, false>(B, lo, 176, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, kGpGlobalNP, is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
         }
         if (rc) return rc;

@@ -44,7 +44,7 @@ static void run_all(int64_t n_obj, const int64_t* offsets, const double* t, cons
 static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux, const double* err,
                    const uint8_t* band, double* out, int32_t* status) {
     using W = WaveHost;
-    constexpr int NP = 1024;
+    constexpr int NP = 768;
     auto ws = std::make_unique<GpLds<NP>>();
     std::vector<double> K((size_t)NP * (NP + 1) / 2);
     for (int64_t i = 0; i < n_obj; ++i) {
