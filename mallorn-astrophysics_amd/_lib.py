@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblcfe.so")
+LIB_PATH = os.environ.get("LCFE_LIB_PATH") or os.path.join(_HERE, "csrc", "liblcfe.so")   # override: instrumented builds
 NUM_SETS = 8
 
 c_i64p = ctypes.POINTER(ctypes.c_int64)

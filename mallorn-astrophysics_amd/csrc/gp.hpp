@@ -20,21 +20,43 @@ constexpr double GP_LOG_2PI = 1.8378770664093453;
 
 LCFE_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; }      // j <= i
 
-constexpr int GP_B = 8;                                      // pivot-block width of the sweep
+#if defined(__HIPCC__)
+typedef __attribute__((address_space(3))) double lds_double;     // LDS-qualified element type: keeps ds_* addressing across calls
+#endif
+
+template <class P> struct gp_is_lds_ptr { static constexpr bool value = false; };
+#if defined(__HIPCC__)
+template <> struct gp_is_lds_ptr<lds_double*> { static constexpr bool value = true; };
+#endif
+
+// pivot-block width of the sweep (16 was measured for the global-scratch tiers: no gain, the
+// update is latency- not bandwidth-bound there)
+template <int NP> struct gp_block { static constexpr int B = 8; };
 
 // Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
 // doubles) lives in LDS for the small tiers and in a per-workgroup slab of global scratch otherwise.
-template <int NP>
+template <int NP, int NW = 4>
 struct GpLds {
     double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
     double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
-    double V[GP_B][NP];                       // pivot-block columns A(:, P)
-    double Wm[GP_B][NP];                      // A(:, P) * A(P,P)^-1
-    double P[GP_B][GP_B];                     // pivot block -> its inverse
+    double V[gp_block<NP>::B][NP];            // pivot-block columns A(:, P)
+    double P[NW][gp_block<NP>::B][gp_block<NP>::B];  // per-wavefront copy of the pivot block -> minus its inverse
+    double Wm[gp_block<NP>::B][NP];           // A(:, P) * A(P,P)^-1
     double lb_s[10][4], lb_y[10][4], lb_rho[10];   // L-BFGS memory (block-uniform, kept out of registers)
     double slot[2];
     double out[GP_NCOL + 1];
+#ifdef LCFE_GP_PROF
+    unsigned long long prof[12];
+#endif
 };
+
+#if defined(LCFE_GP_PROF) && defined(__HIPCC__)
+#define GP_T0() unsigned long long t0__ = __builtin_readcyclecounter()
+#define GP_T(slot_) do { if (W::lane() == 0) { unsigned long long t1__ = __builtin_readcyclecounter(); S.prof[slot_] += t1__ - t0__; t0__ = t1__; } else { t0__ = 0; } } while (0)
+#else
+#define GP_T0() do {} while (0)
+#define GP_T(slot_) do {} while (0)
+#endif
 
 LCFE_FN double gp_wavelength(int band) {
     // multiband_gp.py:26-29
@@ -43,83 +65,137 @@ LCFE_FN double gp_wavelength(int band) {
 }
 
 // In-place inverse of the packed symmetric positive-definite matrix A (lower triangle, row-major)
-// by a BLOCKED SYMMETRIC SWEEP: for each pivot block P of GP_B consecutive indices
+// by a BLOCKED SYMMETRIC SWEEP: for each pivot block P of B consecutive indices
 //     A_PP <- -A_PP^-1 ,  A_RP <- A_RP A_PP^-1 ,  A_RR <- A_RR - A_RP A_PP^-1 A_PR     (R = all other indices)
 // After all blocks A = -K^-1.  The pivots met while inverting the diagonal blocks are exactly the
 // Cholesky pivots L_jj^2, so log|K| = sum log(pivot) and "pivot <= 0" is LAPACK dpotrf's failure
-// (george: log-likelihood = -inf).  n/GP_B block steps, each a fully parallel rank-GP_B update of
-// the whole triangle -- this is what replaces the n sequential columns of a textbook Cholesky.
-template <class W, int NP>
-LCFE_FN bool gp_sweep_inverse(double* A, int n, GpLds<NP>& S, double& logdet) {
+// (george: log-likelihood = -inf).  n/B block steps with two workgroup barriers each; a step is a
+// fully parallel rank-B update of the whole triangle -- this replaces the n sequential columns of
+// a textbook Cholesky + triangular inverse.
+template <class W, int NP, class KP>
+LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logdet) {
+    constexpr int B = gp_block<NP>::B;
     const int lane = W::lane();
-    constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;     // lanes that share one matrix row
+    // lanes that share one matrix row in the rank-B update: short rows for the small tiers
+    constexpr int G0 = (NP <= 64) ? 16 : ((NP <= 128) ? 32 : 64);
+    constexpr int G = (W::LANES >= G0) ? G0 : W::LANES;
     constexpr int RG = W::LANES / G;                        // rows in flight
+    constexpr int U = 2;                                    // independent elements per lane and trip
     const int rl = lane / G, cl = lane % G;
+    double (*Pw)[B] = S.P[W::wave_id()];
     double ld = 0.0;
-    for (int k0 = 0; k0 < n; k0 += GP_B) {
-        const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
-        // (1) V[p][i] = A(i, k0+p) for every i (symmetric access)
-        for (int p = 0; p < bs; ++p) {
-            const int kp = k0 + p;
-            for (int i = lane; i < n; i += W::LANES) S.V[p][i] = (i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)];
+    for (int k0 = 0; k0 < n; k0 += B) {
+        const int bs = (n - k0 < B) ? n - k0 : B;
+        GP_T0();
+        // (1) V[p][i] = A(i, k0+p) for every i (symmetric access); rows p >= bs are zero padding
+        for (int idx = lane; idx < B * NP; idx += W::LANES) {
+            const int p = idx / NP, i = idx - p * NP;       // NP is a compile-time constant
+            if (i < n) {
+                const int kp = k0 + p;
+                S.V[p][i] = (p < bs) ? ((i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)]) : 0.0;
+            }
         }
         W::sync();
-        // (2) P <- A_PP^-1 by an unblocked sweep of the bs x bs block (sign-flipped at the end)
-        for (int e = lane; e < bs * bs; e += W::LANES) S.P[e / bs][e % bs] = S.V[e % bs][k0 + e / bs];
-        W::sync();
-        for (int q = 0; q < bs; ++q) {
-            const double d = S.P[q][q];
-            if (!(d > 0.0)) return false;                   // uniform
-            ld += log(d);
-            constexpr int NV = (GP_B * GP_B + W::LANES - 1) / W::LANES;
+        GP_T(0);
+        // (2) every wavefront inverts its own copy of the (identity-padded) pivot block by B
+        //     single-index sweeps: only wave-level hand-offs, no workgroup barrier
+        for (int e = W::wlane(); e < B * B; e += W::WAVE) {
+            const int a = e / B, b = e % B;
+            Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+        }
+        W::wave_sync();
+        double prod = 1.0;
+        for (int q = 0; q < B; ++q) {
+            const double d = Pw[q][q];
+            if (!(d > 0.0)) return false;                   // identical in every wavefront -> uniform
+            prod *= d;
+            if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }      // one log per 8 pivots (no overflow)
+            const double inv = 1.0 / d;
+            constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
             double nv[NV];
-            int cnt = 0;
-            for (int e = lane; e < bs * bs; e += W::LANES) {
-                const int a = e / bs, b = e % bs;
-                double v;
-                if (a == q && b == q) v = -1.0 / d;
-                else if (a == q) v = S.P[q][b] / d;
-                else if (b == q) v = S.P[a][q] / d;
-                else v = S.P[a][b] - S.P[a][q] * S.P[q][b] / d;
-                nv[cnt++] = v;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int e = W::wlane() + c * W::WAVE;
+                const int a = e / B, b = e % B;
+                const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
+                double v = pab - paq * pqb * inv;
+                if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
+                if (a == q && b == q) v = -inv;
+                nv[c] = v;
             }
-            W::sync();
-            cnt = 0;
-            for (int e = lane; e < bs * bs; e += W::LANES) S.P[e / bs][e % bs] = nv[cnt++];
-            W::sync();
+            W::wave_sync();
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int e = W::wlane() + c * W::WAVE;
+                Pw[e / B][e % B] = nv[c];
+            }
+            W::wave_sync();
         }
-        // now S.P = -A_PP^-1
-        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -S.P)
-        for (int p = 0; p < bs; ++p)
-            for (int i = lane; i < n; i += W::LANES) {
-                double s = 0;
-                for (int q = 0; q < bs; ++q) s -= S.V[q][i] * S.P[q][p];
-                S.Wm[p][i] = s;
+        GP_T(1);
+        // now Pw = -A_PP^-1 (padding: -1 on the diagonal, met only by zero rows of V)
+        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw): one matrix row per lane
+        for (int i = lane; i < n; i += W::LANES) {
+            double vq[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) vq[q] = S.V[q][i];
+#pragma unroll
+            for (int p = 0; p < B; ++p) {
+                double sacc = 0;
+#pragma unroll
+                for (int q = 0; q < B; ++q) sacc = fma(-vq[q], Pw[q][p], sacc);
+                S.Wm[p][i] = sacc;
             }
+        }
         W::sync();
-        // (4) rank-bs update of the whole triangle + the new pivot columns
+        GP_T(2);
+        // (4) rank-B update of every row outside the pivot block (pivot columns are skipped and
+        //     rewritten in (5))
         for (int i = rl; i < n; i += RG) {
-            const int rowi = tri_index(i, 0);
-            const bool i_in = (i >= k0 && i < k0 + bs);
-            double wi[GP_B];
+            if (i >= k0 && i < k0 + bs) continue;
+            double wi[B];
 #pragma unroll
-            for (int p = 0; p < GP_B; ++p) wi[p] = (p < bs) ? S.Wm[p][i] : 0.0;
-            for (int j = cl; j <= i; j += G) {
-                const bool j_in = (j >= k0 && j < k0 + bs);
-                double v;
-                if (i_in && j_in) v = S.P[i - k0][j - k0];                      // -A_PP^-1
-                else if (j_in) v = S.Wm[j - k0][i];                             // A_RP A_PP^-1 (row i below/after the block)
-                else if (i_in) v = S.Wm[i - k0][j];                             // (row i in the block, column j before it)
-                else {
-                    double acc = 0;
+            for (int p = 0; p < B; ++p) wi[p] = S.Wm[p][i];
+            KP row = A + tri_index(i, 0);
+            int j = cl;
+            for (; j + (U - 1) * G <= i; j += U * G) {
+                double v[U][B], x[U], acc[U];
 #pragma unroll
-                    for (int p = 0; p < GP_B; ++p) acc += wi[p] * ((p < bs) ? S.V[p][j] : 0.0);
-                    v = A[rowi + j] - acc;
+                for (int u = 0; u < U; ++u) x[u] = row[j + u * G];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int p = 0; p < B; ++p) v[u][p] = S.V[p][j + u * G];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u] = 0;
+#pragma unroll
+                    for (int p = 0; p < B; ++p) acc[u] = fma(wi[p], v[u][p], acc[u]);
                 }
-                A[rowi + j] = v;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = j + u * G;
+                    if (!(jj >= k0 && jj < k0 + bs)) row[jj] = x[u] - acc[u];
+                }
+            }
+            for (; j <= i; j += G) {
+                double a0 = 0;
+#pragma unroll
+                for (int p = 0; p < B; ++p) a0 = fma(wi[p], S.V[p][j], a0);
+                if (!(j >= k0 && j < k0 + bs)) row[j] -= a0;
+            }
+        }
+        // (5) new pivot rows / columns:  A_RP <- A_RP A_PP^-1 ,  A_PP <- -A_PP^-1  (disjoint from (4))
+        for (int idx = lane; idx < B * NP; idx += W::LANES) {
+            const int p = idx / NP, i = idx - p * NP;
+            if (i < n && p < bs) {
+                const int kp = k0 + p;
+                const bool in_blk = (i >= k0 && i < k0 + bs);
+                const double v = in_blk ? Pw[i - k0][p] : S.Wm[p][i];
+                if (i >= kp) A[tri_index(i, kp)] = v; else if (!in_blk) A[tri_index(kp, i)] = v;
             }
         }
         W::sync();
+        GP_T(3);
     }
     logdet = ld;
     return true;
@@ -136,13 +212,14 @@ LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1,
 // One evaluation of f = -log-likelihood and its gradient at p (george GP.log_likelihood /
 // grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten (by -K^-1).  On a
 // failed factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
-template <class W, int NP>
-LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& f, double g[4], bool need_grad) {
+template <class W, int NP, class KP>
+LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, KP K, double& f, double* g, bool need_grad) {
     const int lane = W::lane();
     constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;
     constexpr int RG = W::LANES / G;
     const int rl = lane / G, cl = lane % G;
     const double mu = p[0], c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
+    GP_T0();
     // Gram matrix, packed lower
     for (int i = rl; i < n; i += RG) {
         const int rowi = tri_index(i, 0);
@@ -157,9 +234,11 @@ LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& 
     }
     for (int i = lane; i < n; i += W::LANES) S.r[i] = S.y[i] - mu;
     W::sync();
+    GP_T(4);
     double logdet;
     g[0] = g[1] = g[2] = g[3] = 0.0;
-    if (!gp_sweep_inverse<W, NP>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
+    if (!gp_sweep_inverse<W, NP, KP>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
+    GP_T(5);      // (sweep total)
     // alpha = K^-1 r = -(A r) with A symmetric packed ; r' K^-1 r = r . alpha
     double ra = 0, sa = 0;
     for (int i = lane; i < n; i += W::LANES) {
@@ -177,6 +256,7 @@ LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& 
     const double ll = -0.5 * (ra + logdet + n * GP_LOG_2PI);
     f = finite_d(ll) ? -ll : 1e25;
     W::sync();
+    GP_T(6);
     if (!need_grad) return;
     // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta ,  Kinv_ij = -K[ij]
     double g1 = 0, g2 = 0, g3 = 0;
@@ -203,6 +283,7 @@ LCFE_FN void gp_eval(const double p[4], int n, GpLds<NP>& S, double* K, double& 
     g[2] = -0.5 * g2;
     g[3] = -0.5 * g3;
     W::sync();
+    GP_T(7);
 }
 
 LCFE_FN bool gp_row_valid(const ObjIn& in, int i) {
@@ -213,11 +294,14 @@ LCFE_FN bool gp_row_valid(const ObjIn& in, int i) {
 
 // multiband_gp.py:292-344 for one object (rows read straight from the CSR slice, file order).
 // `K` points to packed-triangle storage for NP points (LDS or global scratch).
-template <class W, int NP>
-LCFE_FN void gp_object(const ObjIn& L, GpLds<NP>& S, double* K, int32_t* st) {
+template <class W, int NP, class KP>
+LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* st) {
     const int lane = W::lane();
     double* o = S.out;
     for (int k = lane; k < GP_NCOL; k += W::LANES) o[k] = qnan();
+#ifdef LCFE_GP_PROF
+    if (lane == 0) for (int k = 0; k < 12; ++k) S.prof[k] = 0;
+#endif
     // ---- prepare_multiband_data (:34-87): valid rows in file order
     int n = 0;
     double tmin_all = __builtin_inf();
@@ -281,10 +365,13 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP>& S, double* K, int32_t* st) {
     double fval = 0;
     int n_iter = 0, n_eval = 0, why = LB_ERROR;
     if (finite0) {
-        auto ev = [&](const double* x, double& f, double* g) { gp_eval<W, NP>(x, n, S, K, f, g, true); };
+        auto ev = [&](const double* x, double& f, double* g) { gp_eval<W, NP, KP>(x, n, S, K, f, g, true); };
         why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval, S.lb_s, S.lb_y, S.lb_rho);
     }
     if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
+#ifdef LCFE_GP_PROF
+    if (st && lane == 0) for (int k = 0; k < 8; ++k) st[4 + k] = (int)(S.prof[k] >> 10);
+#endif
     if (!finite0 || !(finite_d(p[0]) && finite_d(p[1]) && finite_d(p[2]) && finite_d(p[3]))) { W::sync(); return; }
     // features read params[0..2] of george's vector [mean, log_constant, log_M_0_0, log_M_1_1] (:171-188)
     const double amplitude = exp(p[0]);
@@ -315,7 +402,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP>& S, double* K, int32_t* st) {
     const double peak_time = L.t[pk] - tmin_all;
     // ---- interpolate_multiband (:196-289): alpha at the optimum, then 12 predictions
     double ftmp, gtmp[4];
-    gp_eval<W, NP>(p, n, S, K, ftmp, gtmp, false);
+    gp_eval<W, NP, KP>(p, n, S, K, ftmp, gtmp, false);
     if (ftmp >= 1e25) { W::sync(); return; }          // factorisation failed at the optimum: predict raises -> NaN (:279-287)
     const double c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
     const double EP[4] = {0, 20, 50, 100};

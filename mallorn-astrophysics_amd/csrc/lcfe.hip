@@ -81,16 +81,20 @@ int num_cus(int dev);
 
 // ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 176) or,
 // for longer light curves, in a per-workgroup slab of global scratch.
-constexpr int kGpGlobalNP = 768;
+constexpr int kGpMidNP = 384;       // matrix in global scratch, two workgroups per CU
+constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one workgroup per CU
+constexpr int kGpMidGrid = 512;
 constexpr int kGpGlobalGrid = 256;
+constexpr size_t kGpMidBytes = (size_t)kGpMidGrid * kGpMidNP * (kGpMidNP + 1) / 2 * 8;
+constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8;
 
 template <int NP, bool GLOBAL_K>
-__global__ __launch_bounds__(256) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
+__global__ __launch_bounds__(GLOBAL_K ? 1024 : 256) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch) {
-    using W = BlockDev<256>;
-    __shared__ GpLds<NP> S;
+    using W = BlockDev<(GLOBAL_K ? 1024 : 256)>;
+    __shared__ GpLds<NP, W::NWAVES> S;
     __shared__ double Klds[GLOBAL_K ? 1 : NP * (NP + 1) / 2];
-    double* K = GLOBAL_K ? kscratch + (size_t)blockIdx.x * ((size_t)NP * (NP + 1) / 2) : Klds;
+    double* Kg = kscratch + (size_t)blockIdx.x * ((size_t)NP * (NP + 1) / 2);
     for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
         const int64_t s = B.offsets[i];
         const int64_t n64 = B.offsets[i + 1] - s;
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(256) void gp_kernel(BatchView B, int lo, int hi, in
             continue;
         }
         ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
-        gp_object<W, NP>(in, S, K, st);
+        if constexpr (GLOBAL_K) gp_object<W, NP, double*>(in, S, Kg, st);
+        else gp_object<W, NP, lds_double*>(in, S, (lds_double*)Klds, st);
         store_row<W>(S.out, row, GP_NCOL);
         __syncthreads();
     }
@@ -115,13 +120,14 @@ template <int NP, bool GLOBAL_K>
 int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
                    int st_ld, int st0, hipStream_t stream, int dev, double* kscratch) {
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, 256, 0));
+    constexpr int threads = GLOBAL_K ? 1024 : 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, threads, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
-    if (GLOBAL_K && grid > kGpGlobalGrid) grid = kGpGlobalGrid;
+    if (GLOBAL_K && grid > (NP == kGpMidNP ? kGpMidGrid : kGpGlobalGrid)) grid = (NP == kGpMidNP ? kGpMidGrid : kGpGlobalGrid);
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(256), 0, stream, B, lo, hi, last, out, ld,
+    hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(threads), 0, stream, B, lo, hi, last, out, ld,
                        col0, status, st_ld, st0, kscratch);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -132,8 +138,8 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
     const int caps[4] = {64, 120, 176, kGpGlobalNP};
     int last = 0;
     while (last < 3 && caps[last] < max_len) ++last;
-    if (last == 3 && kscratch_bytes < (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8)
-        return fail_msg("lcfe_extract_device: workspace too small for the GP global tier");
+    if (last >= 3 && kscratch_bytes < kGpMidBytes + kGpGlobalBytes)
+        return fail_msg("lcfe_extract_device: workspace too small for the GP global tiers");
     int lo = -1;
     for (int ti = 0; ti <= last; ++ti) {
         const int is_last = (ti == last);
@@ -142,7 +148,7 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
             case 0: rc = launch_gp_tier<64, false>(B, lo, 64, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 1: rc = launch_gp_tier<120, false>(B, lo, 120, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 2: rc = launch_gp_tier<176, false>(B, lo, 176, is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, kGpGlobalNP, is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
+            case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, kGpGlobalNP, is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch + kGpMidBytes / 8); break;
         }
         if (rc) return rc;
         ++*n_launch;
@@ -270,7 +276,7 @@ const char* lcfe_colname(int mask, int64_t j) {
 
 size_t lcfe_workspace_bytes(int mask, int64_t, int64_t) {
     size_t b = 256;
-    if (mask & (1 << SET_GP2D)) b += (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8;
+    if (mask & (1 << SET_GP2D)) b += kGpMidBytes + kGpGlobalBytes;
     return b;
 }
 

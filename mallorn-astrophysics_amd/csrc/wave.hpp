@@ -30,6 +30,16 @@ struct WaveDev {
     static __device__ __forceinline__ int lane() { return threadIdx.x; }
     // LDS fence between cross-lane producer/consumer phases (workgroup == one wave)
     static __device__ __forceinline__ void sync() { __syncthreads(); }
+    // sub-group view used by code that lets every WAVEFRONT of a workgroup work redundantly
+    static constexpr int WAVE = 64;
+    static constexpr int NWAVES = 1;
+    static __device__ __forceinline__ int wave_id() { return 0; }
+    static __device__ __forceinline__ int wlane() { return threadIdx.x; }
+    static __device__ __forceinline__ void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     static __device__ __forceinline__ double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
     static __device__ __forceinline__ double sum(double v) {
@@ -81,8 +91,19 @@ template <int T>
 struct BlockDev {
     static constexpr int LANES = T;
     static constexpr int NW = T / 64;
+    static constexpr int WAVE = 64;
+    static constexpr int NWAVES = T / 64;
     static __device__ __forceinline__ int lane() { return threadIdx.x; }
     static __device__ __forceinline__ void sync() { __syncthreads(); }
+    static __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+    static __device__ __forceinline__ int wlane() { return threadIdx.x & 63; }
+    // LDS hand-off between lanes of ONE wavefront: LDS operations of a wave execute in order, so
+    // only the compiler has to be kept from reordering across this point
+    static __device__ __forceinline__ void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     template <class V, class Op>
     static __device__ __forceinline__ V reduce(V v, Op op) {
         __shared__ V part[NW];
@@ -109,8 +130,13 @@ struct BlockDev {
 
 struct WaveHost {
     static constexpr int LANES = 1;
+    static constexpr int WAVE = 1;
+    static constexpr int NWAVES = 1;
     static int lane() { return 0; }
     static void sync() {}
+    static int wave_id() { return 0; }
+    static int wlane() { return 0; }
+    static void wave_sync() {}
     static double sum(double v) { return v; }
     static double max(double v) { return v; }
     static double min(double v) { return v; }

@@ -40,18 +40,24 @@ static void run_all(int64_t n_obj, const int64_t* offsets, const double* t, cons
     }
 }
 
-// the GP kernel has its own working set (Gram matrix) and reads the CSR slice directly
+// the GP kernel has its own working set (Gram matrix) and reads the CSR slice directly; like the
+// device it uses the 8-wide sweep for short light curves and the 16-wide one for long ones
 static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux, const double* err,
                    const uint8_t* band, double* out, int32_t* status) {
     using W = WaveHost;
-    constexpr int NP = 768;
-    auto ws = std::make_unique<GpLds<NP>>();
-    std::vector<double> K((size_t)NP * (NP + 1) / 2);
+    constexpr int NS = 176, NL = 768;
+    auto ws = std::make_unique<GpLds<NS, 1>>();
+    auto wl = std::make_unique<GpLds<NL, 1>>();
+    std::vector<double> K((size_t)NL * (NL + 1) / 2);
     for (int64_t i = 0; i < n_obj; ++i) {
         const int64_t s = offsets[i];
-        ObjIn in{t + s, flux + s, err + s, band + s, (int)(offsets[i + 1] - s), qnan()};
-        gp_object<W, NP>(in, *ws, K.data(), status ? status + 4 * i : nullptr);
-        for (int k = 0; k < GP_NCOL; ++k) out[i * GP_NCOL + k] = ws->out[k];
+        const int n = (int)(offsets[i + 1] - s);
+        ObjIn in{t + s, flux + s, err + s, band + s, n, qnan()};
+        int32_t* st = status ? status + set_nstatus(SET_GP2D) * i : nullptr;
+        const double* o;
+        if (n <= NS) { gp_object<W, NS, double*>(in, *ws, K.data(), st); o = ws->out; }
+        else { gp_object<W, NL, double*>(in, *wl, K.data(), st); o = wl->out; }
+        for (int k = 0; k < GP_NCOL; ++k) out[i * GP_NCOL + k] = o[k];
     }
 }
 
