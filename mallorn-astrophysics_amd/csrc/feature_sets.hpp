@@ -96,6 +96,13 @@ LCFE_FN void fill_row_nan(double* row, int ncol) {
 template <class W, int SET, int CAP>
 struct RunSet;
 
+// policy of one bounded fit inside a wave: on the device the six band fits of a light curve run
+// side by side in 8-lane groups; the host simulation runs them one after the other
+template <class W> struct FitPolicy { using type = W; };
+#if defined(__HIPCC__)
+template <> struct FitPolicy<WaveDev> { using type = GroupDev<8>; };
+#endif
+
 template <class W, int CAP>
 struct RunSet<W, SET_STAT, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
@@ -110,7 +117,7 @@ template <class W, int CAP>
 struct RunSet<W, SET_BAZIN, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_BAZIN, CAP>& ws, double* row, int32_t* st) {
         stage_object<W, CAP>(in, ws.obj);
-        bazin_object<W, CAP>(ws.obj, ws.fit, st);
+        bazin_object<typename FitPolicy<W>::type, W, CAP>(ws.obj, ws.fit, st);
         store_row<W>(ws.fit.out, row, BAZIN_NCOL);
         W::sync();
     }

@@ -67,17 +67,31 @@ struct BazinModel {
     }
 };
 
+// The six band fits of one light curve share one pool: band k (rows boff[k]..boff[k+1]) owns the
+// rows boff[k] + 5k .. of every column, so the fits can run side by side in different lane groups.
 template <int CAP>
 struct BazinLds {
-    TrfLds<5, CAP> trf;
-    double slot[2];
+    double A[6][CAP + 30];
+    double r[CAP], rn[CAP], w[CAP];
+    double slot[8][2];
     double out[BAZIN_NCOL];
 };
 
+template <int CAP>
+LCFE_FN TrfView<5> bazin_view(BazinLds<CAP>& S, int band, int band_start) {
+    TrfView<5> v;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v.A[k] = S.A[k] + band_start + 5 * band;
+    v.r = S.r + band_start;
+    v.rn = S.rn + band_start;
+    v.w = S.w + band_start;
+    return v;
+}
+
 // bazin_fitting.py:63-179 for one band's time-sorted rows -> out8 (wave-shared, lane 0 writes)
-template <class W, int CAP>
+template <class W, class Store>
 LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double* e, int m,
-                                 BazinLds<CAP>& S, double* out8) {
+                                 Store& V, double* slot, double* out8) {
     const int lane = W::lane();
     TrfResult res{TRF_FAIL_TOO_FEW, 0};
     if (m < 5) {                                                   // :76-87
@@ -85,7 +99,7 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
         return res;
     }
     const int pk = wave_argmax_first<W>(f, m);                     // :97  np.argmax on the sorted rows
-    const double med = wave_median<W>(f, m, S.slot);               // :99-100
+    const double med = wave_median<W>(f, m, slot);                 // :99-100
     const double fpk = f[pk];
     const double duration = t[m - 1] - t[0];                       // :103
     double mx = -__builtin_inf();
@@ -99,10 +113,10 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
     ub[0] = 3 * mx; ub[1] = t[m - 1]; ub[2] = duration; ub[3] = duration; ub[4] = 2 * mx;
     for (int i = lane; i < m; i += W::LANES) {
         const double sg = (e[i] > 0) ? e[i] : 1.0;                 // :126
-        S.trf.w[i] = 1.0 / sg;                                     // _minpack_py.py:981 transform = 1/sigma
+        V.w[i] = 1.0 / sg;                                         // _minpack_py.py:981 transform = 1/sigma
     }
     W::sync();
-    res = trf_fit<W, BazinModel, CAP>(BazinModel(), t, f, m, x, lb, ub, 2000, S.trf);
+    res = trf_fit<W, BazinModel, Store>(BazinModel(), t, f, m, x, lb, ub, 2000, V);
     if (res.status <= 0) {                                         // :168-179 any exception -> NaN
         if (lane == 0) for (int k = 0; k < 8; ++k) out8[k] = qnan();
         return res;
@@ -141,16 +155,19 @@ LCFE_FN void mean_std_small(const double* v, int n, double& mean, double& sd) {
 }
 
 // bazin_fitting.py:182-251
-template <class W, int CAP>
+// W: the policy of ONE FIT (a whole wave, or an 8-lane group: then the six bands run side by side
+// in six groups of the wave).  WW: the policy of the whole wave (cross-band epilogue).
+template <class W, class WW, int CAP>
 LCFE_FN void bazin_object(const ObjLds<CAP>& L, BazinLds<CAP>& S, int32_t* st) {
-    const int lane = W::lane();
-    for (int k = 0; k < 6; ++k) {
+    for (int k = W::group_id(); k < 6; k += W::NGROUPS) {
         const int s = L.boff[k], m = L.boff[k + 1] - s;
-        TrfResult r = bazin_fit_band<W, CAP>(L.bt + s, L.bf + s, L.be + s, m, S, S.out + 8 * k);
-        if (st && lane == 0) { st[2 * k] = r.status; st[2 * k + 1] = r.nfev; }
+        TrfView<5> V = bazin_view(S, k, s);
+        TrfResult r = bazin_fit_band<W, TrfView<5>>(L.bt + s, L.bf + s, L.be + s, m, V, S.slot[W::group_id()], S.out + 8 * k);
+        if (st && W::lane() == 0) { st[2 * k] = r.status; st[2 * k + 1] = r.nfev; }
         W::sync();
     }
-    if (lane == 0) {
+    WW::sync();
+    if (WW::lane() == 0) {
         double* o = S.out;
         double v[6];
         int n = 0;
@@ -164,7 +181,7 @@ LCFE_FN void bazin_object(const ObjLds<CAP>& L, BazinLds<CAP>& S, int32_t* st) {
         for (int k = 0; k < 6; ++k) if (!is_nan(o[8 * k + 5])) v[n++] = o[8 * k + 5];       // :238-249
         if (n > 0) { mean_std_small(v, n, mean, sd); o[50] = mean; o[51] = sd; } else { o[50] = qnan(); o[51] = qnan(); }
     }
-    W::sync();
+    WW::sync();
 }
 
 // ---------------------------------------------------------------- post-peak decline models
@@ -234,7 +251,7 @@ LCFE_FN TrfResult decline_fit(int k, double peak_flux, double mean_post, double 
     for (int i = lane; i < k; i += W::LANES) T.w[i] = 1.0;        // unweighted: r = model - y
     W::sync();
     M model;
-    TrfResult res = trf_fit<W, M, CAP>(model, S.tp, S.fp, k, x, lb, ub, 1000, T);
+    TrfResult res = trf_fit<W, M, TrfLds<N, CAP>>(model, S.tp, S.fp, k, x, lb, ub, 1000, T);
     if (res.status <= 0) {                                        // :191-192
         if (lane == 0) *out = qnan();
         return res;

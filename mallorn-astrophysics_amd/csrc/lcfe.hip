@@ -51,15 +51,27 @@ struct BatchView {
 // One launch = one (feature set, LDS tier): objects with lo < n <= CAP are processed, others are
 // left to the other tiers; n > hi_all (longer than the largest tier) gets NaN + status -100 from
 // the largest tier.
+// Objects are handed out through a device-side ticket counter (`ticket`, zeroed before the launch)
+// when one is supplied -- fit costs are heavy-tailed (nfev 5..2000), so a static round-robin would
+// leave most waves idle behind the unluckiest one -- else by a plain grid stride.
 template <int SET, int CAP>
 __global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_tier, double* out,
                                                  int ld, int col0, int32_t* status, int st_ld,
-                                                 int st0) {
+                                                 int st0, unsigned long long* ticket) {
     __shared__ SetLds<SET, CAP> ws;
+    __shared__ long long next_obj;
     using W = WaveDev;
     const int ncol = set_ncols(SET);
     const int nst = set_nstatus(SET);
-    for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
+    int64_t i = blockIdx.x;
+    for (;; i += gridDim.x) {
+        if (ticket) {
+            if (threadIdx.x == 0) next_obj = (long long)atomicAdd(ticket, 1ull);
+            __syncthreads();
+            i = next_obj;
+            __syncthreads();
+        }
+        if (i >= B.n_obj) break;
         const int64_t s = B.offsets[i];
         const int64_t n64 = B.offsets[i + 1] - s;
         if (n64 <= lo) continue;
@@ -176,15 +188,16 @@ int num_cus(int dev) {
 
 template <int SET, int CAP>
 int launch_tier(const BatchView& B, int lo, int last, double* out, int ld, int col0, int32_t* status,
-                int st_ld, int st0, hipStream_t stream, int dev) {
+                int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, set_kernel<SET, CAP>, 64, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
+    if (ticket) HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL((set_kernel<SET, CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, lo, last, out,
-                       ld, col0, status, st_ld, st0);
+                       ld, col0, status, st_ld, st0, ticket);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -197,7 +210,7 @@ constexpr int max_tier() {
 
 template <int SET>
 int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status,
-               int st_ld, int st0, hipStream_t stream, int dev, int* n_launch) {
+               int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
     // tiers needed: every tier whose window (prev_cap, cap] can contain an object, i.e. up to the
     // first cap >= max_len; the last launched tier also NaN-fills objects longer than its cap.
     int last = 0;
@@ -207,13 +220,13 @@ int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col
         const int is_last = (ti == last);
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_tier<SET, 128>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
-            case 1: rc = launch_tier<SET, 256>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
-            case 2: rc = launch_tier<SET, 512>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
-            case 3: rc = launch_tier<SET, 1024>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev); break;
+            case 0: rc = launch_tier<SET, 128>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 0 : nullptr); break;
+            case 1: rc = launch_tier<SET, 256>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 1 : nullptr); break;
+            case 2: rc = launch_tier<SET, 512>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 2 : nullptr); break;
+            case 3: rc = launch_tier<SET, 1024>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 3 : nullptr); break;
             case 4:
                 if constexpr (max_tier<SET>() >= 4)
-                    rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev);
+                    rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 4 : nullptr);
                 break;
         }
         if (rc) return rc;
@@ -230,6 +243,16 @@ bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
 }  // namespace
 
 extern "C" {
+
+#ifdef LCFE_TRF_PROF
+// debug builds only: read and reset the TRF phase counters
+int lcfe_debug_trf_prof(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lcfe::g_trf_prof), 64) != hipSuccess) return 1;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lcfe::g_trf_prof), z, 64) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 
 int lcfe_version(void) { return 1; }
 
@@ -275,7 +298,7 @@ const char* lcfe_colname(int mask, int64_t j) {
 }
 
 size_t lcfe_workspace_bytes(int mask, int64_t, int64_t) {
-    size_t b = 256;
+    size_t b = 1024;
     if (mask & (1 << SET_GP2D)) b += kGpMidBytes + kGpGlobalBytes;
     return b;
 }
@@ -305,6 +328,10 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         prof->bytes_in = 25 * n_points + 8 * (n_obj + 1) + (d_z ? 8 * n_obj : 0);
         prof->bytes_out = 8 * n_obj * (int64_t)ld;
     }
+    // workspace layout: [0, 1 KiB) ticket counters (8 per set), then the GP scratch slabs
+    unsigned long long* tickets = (d_workspace && workspace_bytes >= 1024) ? (unsigned long long*)d_workspace : nullptr;
+    double* gp_scratch = (d_workspace && workspace_bytes > 1024) ? (double*)((char*)d_workspace + 1024) : nullptr;
+    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - 1024 : 0;
     hipEvent_t ev[NUM_SETS + 1];
     if (prof)
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
@@ -315,16 +342,16 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if (prof) HIP_TRY(hipEventRecord(ev[ne], stream));
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_TDE: rc = launch_set<SET_TDE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_COLOR: rc = launch_set<SET_COLOR>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
-            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl); break;
+            case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_TDE: rc = launch_set<SET_TDE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_COLOR: rc = launch_set<SET_COLOR>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
             case SET_GP2D:
-                rc = launch_gp(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, (double*)d_workspace,
-                               d_workspace ? workspace_bytes : 0, &nl);
+                rc = launch_gp(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, gp_scratch,
+                               gp_scratch_bytes, &nl);
                 break;
         }
         if (rc) return rc;

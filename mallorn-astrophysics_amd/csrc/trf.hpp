@@ -202,6 +202,9 @@ LCFE_FN void jacobi_svd(const TriFactor<N>& T, const Vec<N>& q, double sv[N], do
             }
         }
         if (!rotated) break;
+#ifdef LCFE_TRF_TRACE
+        if (sweep >= 8) printf("   jacobi sweep %d\n", sweep);
+#endif
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -411,14 +414,34 @@ struct TrfResult {
     int nfev;
 };
 
+#if defined(LCFE_TRF_PROF) && defined(__HIPCC__)
+__device__ unsigned long long g_trf_prof[8];
+#define TRF_T0() unsigned long long tt0__ = __builtin_readcyclecounter()
+#define TRF_T(slot_) do { unsigned long long tt1__ = __builtin_readcyclecounter(); if (W::lane() == 0) atomicAdd(&g_trf_prof[slot_], tt1__ - tt0__); tt0__ = tt1__; } while (0)
+#else
+#define TRF_T0() do {} while (0)
+#define TRF_T(slot_) do {} while (0)
+#endif
+
 // Model concept:  static constexpr int NP;  LCFE_FN double operator()(double t, const Vec<NP>& p) const
 //
 // Fits  r_i(x) = w_i*(model(t_i;x) - y_i), i < m.  t, y are wave-shared arrays (LDS); S.w must hold
 // the weights.  x holds p0 on entry and the solution on exit (wave-uniform).
-template <class W, class Model, int CAP>
+//
+// Store: anything with S.A[k][i] (k <= NP columns of m + NP rows), S.r[i], S.rn[i], S.w[i] -- a
+// TrfLds block, or a TrfView of pointers into a pool shared by the bands of one light curve.
+template <int N>
+struct TrfView {
+    double* A[N + 1];
+    double* r;
+    double* rn;
+    double* w;
+};
+
+template <class W, class Model, class Store>
 LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, int m,
                           Vec<Model::NP>& x, const Vec<Model::NP>& lb, const Vec<Model::NP>& ub, int max_nfev,
-                          TrfLds<Model::NP, CAP>& S) {
+                          Store& S) {
     constexpr int N = Model::NP;
     const int lane = W::lane();
     const int M = m + N;
@@ -514,6 +537,7 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
 
     while (true) {
+        TRF_T0();
         cl_scaling();
         double g_norm = 0;
 #pragma unroll
@@ -547,6 +571,7 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
             }
         }
         W::sync();
+        TRF_T(0);
         // ---- Householder QR (in place); R and Q^T f end in rows 0..N-1
         TriFactor<N> T;
         Vec<N> qtf;
@@ -599,8 +624,10 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
 #pragma unroll
             for (int j = 0; j < N; ++j)
                 if (j < i) T.R[i][j] = 0.0;
+        TRF_T(1);
         double sv[N], Vm[N][N], uf[N];
         jacobi_svd<N>(T, qtf, sv, Vm, uf);
+        TRF_T(2);
 #ifdef LCFE_TRF_TRACE
         printf("   sv="); for (int i = 0; i < N; ++i) printf("%.17g ", sv[i]);
         printf(" uf="); for (int i = 0; i < N; ++i) printf("%.17g ", uf[i]);
@@ -619,6 +646,7 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
 #pragma unroll
             for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
             double predicted;
+            TRF_T(3);
             if (!select_step<N>(x, T, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h, predicted)) {
                 res.status = TRF_FAIL_GEOMETRY;
                 return res;
@@ -626,10 +654,12 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
 #pragma unroll
             for (int i = 0; i < N; ++i) x_new[i] = x[i] + step[i];
             make_strictly_feasible(x_new, lb, ub, 0.0);
+            TRF_T(4);
             double c2;
             bool f_ok;
             residual(x_new, S.rn, c2, f_ok);
             res.nfev += 1;
+            TRF_T(5);
             const double step_h_norm = vnorm(step_h);
             if (!f_ok) { Delta = 0.25 * step_h_norm; continue; }
             cost_new = 0.5 * c2;
@@ -661,7 +691,9 @@ LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, 
             W::sync();
             // scipy recomputes J here even when terminating; curve_fit then takes an SVD of it
             // (check_finite) -> a non-finite final Jacobian is a failure too.
+            TRF_T(6);
             jacobian(x, g, fin);
+            TRF_T(7);
             if (!fin) { res.status = TRF_FAIL_NONFINITE; return res; }
         }
     }

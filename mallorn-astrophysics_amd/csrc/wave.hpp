@@ -33,6 +33,8 @@ struct WaveDev {
     // sub-group view used by code that lets every WAVEFRONT of a workgroup work redundantly
     static constexpr int WAVE = 64;
     static constexpr int NWAVES = 1;
+    static constexpr int NGROUPS = 1;      // independent lane groups (see GroupDev)
+    static __device__ __forceinline__ int group_id() { return 0; }
     static __device__ __forceinline__ int wave_id() { return 0; }
     static __device__ __forceinline__ int wlane() { return threadIdx.x; }
     static __device__ __forceinline__ void wave_sync() {
@@ -85,6 +87,55 @@ struct WaveDev {
 #endif
 
 #if defined(__HIPCC__)
+// GS consecutive lanes of a wavefront working on ONE fit while the other groups of the same wave
+// work on other fits (the bands of one light curve).  Groups diverge freely: nothing here uses a
+// wave-wide collective or a hardware barrier.  Reductions are DPP moves inside an 8-lane group
+// (quad_perm swaps, then row_half_mirror) -- no LDS traffic.
+template <int GS>
+struct GroupDev {
+    static_assert(GS == 8, "DPP pattern below is written for 8-lane groups");
+    static constexpr int LANES = GS;
+    static constexpr int NGROUPS = 64 / GS;
+    static constexpr int WAVE = 64;
+    static constexpr int NWAVES = 1;
+    static __device__ __forceinline__ int lane() { return threadIdx.x & (GS - 1); }
+    static __device__ __forceinline__ int group_id() { return (threadIdx.x & 63) / GS; }
+    static __device__ __forceinline__ int wave_id() { return 0; }
+    static __device__ __forceinline__ int wlane() { return threadIdx.x & 63; }
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    static __device__ __forceinline__ void wave_sync() { sync(); }
+    template <int CTRL>
+    static __device__ __forceinline__ double dpp(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)b, hi = (int)(b >> 32);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    template <int CTRL>
+    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+    // quad_perm(1,0,3,2) = 0xB1, quad_perm(2,3,0,1) = 0x4E, row_half_mirror = 0x141
+    template <class V, class Op>
+    static __device__ __forceinline__ V reduce(V v, Op op) {
+        v = op(v, dpp<0xB1>(v));
+        v = op(v, dpp<0x4E>(v));
+        v = op(v, dpp<0x141>(v));
+        return v;
+    }
+    static __device__ __forceinline__ double sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+    static __device__ __forceinline__ double max(double v) { return reduce(v, [](double a, double b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ double min(double v) { return reduce(v, [](double a, double b) { return (b < a) ? b : a; }); }
+    static __device__ __forceinline__ int sum(int v) { return reduce(v, [](int a, int b) { return a + b; }); }
+    static __device__ __forceinline__ int max(int v) { return reduce(v, [](int a, int b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ int min(int v) { return reduce(v, [](int a, int b) { return (b < a) ? b : a; }); }
+    static __device__ __forceinline__ bool any(bool p) { return max(p ? 1 : 0) != 0; }
+    static __device__ __forceinline__ bool all(bool p) { return min(p ? 1 : 0) != 0; }
+};
+
 // A workgroup of T threads (T/64 wavefronts) working on one object: the GP kernel's policy.
 // Reductions go through the wave shuffle network and a small LDS exchange (two barriers each).
 template <int T>
@@ -132,6 +183,8 @@ struct WaveHost {
     static constexpr int LANES = 1;
     static constexpr int WAVE = 1;
     static constexpr int NWAVES = 1;
+    static constexpr int NGROUPS = 1;
+    static int group_id() { return 0; }
     static int lane() { return 0; }
     static void sync() {}
     static int wave_id() { return 0; }
