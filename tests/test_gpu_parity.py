@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP path through the C-ABI against the golden fixtures (real
 reference outputs) and against the oracle on seeded synthetic inputs.  Need an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -198,3 +200,33 @@ def test_gp2d_long_objects_use_global_tier():
     ref = oracle.extract("gp2d", lc)
     bad = parity.compare(got, ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
     assert len(bad) <= 2, "\n".join(bad)
+
+
+def test_entry_point_scripts_write_the_caches(tmp_path):
+    """scripts/precompute_features.py and scripts/cache_bazin_features.py on a synthetic data set
+    laid out like the competition data; the pickles must have the layout the train_v*.py scripts read."""
+    import pickle
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    from mallorn_astrophysics_amd.utils.data_loader import write_synthetic_dataset
+    write_synthetic_dataset(tmp_path, n_train=24, n_test=30, seed=3)
+    env = dict(os.environ, LCFE_DATA_ROOT=str(tmp_path))
+    for script in ("precompute_features.py", "cache_bazin_features.py"):
+        r = subprocess.run([_sys.executable, os.path.join(ROOT, "scripts", script)], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    proc = tmp_path / "data" / "processed"
+    v4 = pickle.load(open(proc / "features_v4_cache.pkl", "rb"))
+    assert set(v4) == {"train_features", "test_features"}
+    assert v4["train_features"].shape == (24, 1 + 123 + 4 + 83 + 65 + 32)
+    assert len(v4["test_features"]) == 30
+    for name, ncol in (("tde_physics_cache.pkl", 25), ("multiband_gp_cache.pkl", 27), ("bazin_features_cache.pkl", 52),
+                       ("enhanced_colors_cache.pkl", 83)):
+        c = pickle.load(open(proc / name, "rb"))
+        assert set(c) == {"train", "test"} and c["train"].shape == (24, ncol + 1), name
+    pw = pickle.load(open(proc / "powerlaw_features.pkl", "rb"))
+    assert pw.shape == (24, 28)
+    # second run: every cache is skipped
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, "scripts", "precompute_features.py")], env=env,
+                       capture_output=True, text=True)
+    assert r.stdout.count("already cached") == 6
