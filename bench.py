@@ -23,7 +23,14 @@ HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_M
 NCOLS = {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65, "physics": 32, "gp2d": 27}
 
 
-_CPU_LC = None      # sample batch inherited by the forked workers (never pickled per job)
+_CPU_LC = None      # sample batch of a CPU-baseline worker
+
+
+def _cpu_init(path):
+    global _CPU_LC
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    g = np.load(path)
+    _CPU_LC = {k: g[k] for k in g.files}
 
 
 def _cpu_worker(args):
@@ -42,7 +49,6 @@ def _take_objects(lc, n):
 
 def cpu_baseline(sets, lc, budget_s=12.0):
     """Time the oracle (kind "port") on the host cores over a bounded sample of the same workload."""
-    global _CPU_LC
     import multiprocessing as mp
     import oracle
 
@@ -56,14 +62,27 @@ def cpu_baseline(sets, lc, budget_s=12.0):
     per_obj = (time.perf_counter() - t0) / pilot
     sample = int(max(cores * 2, min(n_obj, budget_s * cores / max(per_obj, 1e-6))))
     sample = min(sample, n_obj)
-    _CPU_LC = _take_objects(lc, sample)
+    # fresh (spawned) worker processes that never see the GPU runtime or the parent's BLAS threads;
+    # the sample travels through a file, not through per-job pickles
+    import tempfile
+    tmp = tempfile.NamedTemporaryFile(suffix=".npz", delete=False)
+    tmp.close()
+    np.savez(tmp.name, **_take_objects(lc, sample))
     chunk = max(1, sample // (cores * 4))
     jobs = [(s, lo, min(lo + chunk, sample)) for s in sets for lo in range(0, sample, chunk)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
+    # the workers are plain CPU processes: keep profiler / GPU-tool preloads out of their environment
+    saved = {k: os.environ.pop(k) for k in list(os.environ)
+             if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX"))}
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    pool_cm = mp.get_context("spawn").Pool(cores, initializer=_cpu_init, initargs=(tmp.name,))
+    os.environ.pop("HIP_VISIBLE_DEVICES", None)
+    os.environ.update(saved)
+    with pool_cm as pool:
+        pool.map(_cpu_worker, jobs[:cores])            # untimed: process start-up + imports
+        t0 = time.perf_counter()
         pool.map(_cpu_worker, jobs)
-    dt = time.perf_counter() - t0
-    _CPU_LC = None
+        dt = time.perf_counter() - t0
+    os.unlink(tmp.name)
     return {"value": sample / dt, "unit": "light curves/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} objects of the benchmark batch, sets {'+'.join(sets)}, "
                       f"multiprocessing.Pool({cores}) over the numpy/scipy oracle",
