@@ -103,11 +103,13 @@ template <class W> struct FitPolicy { using type = W; };
 template <> struct FitPolicy<WaveDev> { using type = GroupDev<8>; };
 #endif
 
+
+
 template <class W, int CAP>
 struct RunSet<W, SET_STAT, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
-        stat_object<W, CAP>(ws.obj, ws.stat);
+        stat_object<W, typename FitPolicy<W>::type, CAP>(ws.obj, ws.stat);
         store_row<W>(ws.stat.out, row, STAT_NCOL);
         W::sync();
     }
@@ -155,7 +157,7 @@ template <class W, int CAP>
 struct RunSet<W, SET_SHAPE, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_SHAPE, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
-        shape_object<W, CAP>(ws.obj, ws.s);
+        shape_object<W, typename FitPolicy<W>::type, CAP>(ws.obj, ws.s);
         store_row<W>(ws.s.out, row, SHAPE_NCOL);
         W::sync();
     }

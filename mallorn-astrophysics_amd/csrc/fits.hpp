@@ -12,48 +12,25 @@ constexpr int POWERLAW_NCOL = 27;
 // np.clip with NaN propagation
 LCFE_FN double np_clip(double x, double lo, double hi) { return is_nan(x) ? x : fmin(fmax(x, lo), hi); }
 
-// np.median of m wave-shared values (m >= 1) by rank counting; uniform result.  `slot` = 2 doubles
-// of wave-shared scratch.
+// np.median of m wave-shared values (m >= 1) by rank counting; uniform result.  `slot` = 2 doubles,
+// `keys` = m words of wave-shared scratch.
 template <class W>
-LCFE_FN double wave_median(const double* x, int m, double* slot) {
-    const int lo = (m - 1) / 2, hi = m / 2;
+LCFE_FN double wave_median(const double* x, int m, double* slot, unsigned long long* keys) {
+    const int ranks[2] = {(m - 1) / 2, m / 2};
     bool nanf = false;
-    for (int i = W::lane(); i < m; i += W::LANES) {
-        const double xi = x[i];
-        nanf = nanf || is_nan(xi);
-        const uint64_t ki = sort_key(xi);
-        int clt = 0, cle = 0;
-        for (int j = 0; j < m; ++j) {
-            const uint64_t kj = sort_key(x[j]);
-            clt += (kj < ki);
-            cle += (kj <= ki);
-        }
-        if (clt <= lo && lo < cle) slot[0] = xi;
-        if (clt <= hi && hi < cle) slot[1] = xi;
-    }
-    W::sync();
-    const double med = (lo == hi) ? slot[0] : (slot[0] + slot[1]) / 2.0;
+    for (int i = W::lane(); i < m; i += W::LANES) nanf = nanf || is_nan(x[i]);
+    wave_select_ranks<W, 2>(x, m, keys, ranks, slot);
+    const double med = (ranks[0] == ranks[1]) ? slot[0] : (slot[0] + slot[1]) / 2.0;
     const bool any_nan = W::any(nanf);
     W::sync();
     return any_nan ? qnan() : med;
 }
 
-// Values of ranks lo and hi (0-based, sort order of sort_key) among n wave-shared values -> slot[0], slot[1]
+// Values of ranks lo and hi among n wave-shared values -> slot[0], slot[1]
 template <class W>
-LCFE_FN void wave_rank_select(const double* x, int n, int lo, int hi, double* slot) {
-    for (int i = W::lane(); i < n; i += W::LANES) {
-        const double xi = x[i];
-        const uint64_t ki = sort_key(xi);
-        int clt = 0, cle = 0;
-        for (int j = 0; j < n; ++j) {
-            const uint64_t kj = sort_key(x[j]);
-            clt += (kj < ki);
-            cle += (kj <= ki);
-        }
-        if (clt <= lo && lo < cle) slot[0] = xi;
-        if (clt <= hi && hi < cle) slot[1] = xi;
-    }
-    W::sync();
+LCFE_FN void wave_rank_select(const double* x, int n, int lo, int hi, double* slot, unsigned long long* keys) {
+    const int ranks[2] = {lo, hi};
+    wave_select_ranks<W, 2>(x, n, keys, ranks, slot);
 }
 
 // ---------------------------------------------------------------- Bazin
@@ -73,6 +50,7 @@ template <int CAP>
 struct BazinLds {
     double A[6][CAP + 30];
     double r[CAP], rn[CAP], w[CAP];
+    unsigned long long keys[CAP];
     double slot[8][2];
     double out[BAZIN_NCOL];
 };
@@ -91,7 +69,7 @@ LCFE_FN TrfView<5> bazin_view(BazinLds<CAP>& S, int band, int band_start) {
 // bazin_fitting.py:63-179 for one band's time-sorted rows -> out8 (wave-shared, lane 0 writes)
 template <class W, class Store>
 LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double* e, int m,
-                                 Store& V, double* slot, double* out8) {
+                                 Store& V, double* slot, unsigned long long* keys, double* out8) {
     const int lane = W::lane();
     TrfResult res{TRF_FAIL_TOO_FEW, 0};
     if (m < 5) {                                                   // :76-87
@@ -99,7 +77,7 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
         return res;
     }
     const int pk = wave_argmax_first<W>(f, m);                     // :97  np.argmax on the sorted rows
-    const double med = wave_median<W>(f, m, slot);                 // :99-100
+    const double med = wave_median<W>(f, m, slot, keys);           // :99-100
     const double fpk = f[pk];
     const double duration = t[m - 1] - t[0];                       // :103
     double mx = -__builtin_inf();
@@ -162,7 +140,7 @@ LCFE_FN void bazin_object(const ObjLds<CAP>& L, BazinLds<CAP>& S, int32_t* st) {
     for (int k = W::group_id(); k < 6; k += W::NGROUPS) {
         const int s = L.boff[k], m = L.boff[k + 1] - s;
         TrfView<5> V = bazin_view(S, k, s);
-        TrfResult r = bazin_fit_band<W, TrfView<5>>(L.bt + s, L.bf + s, L.be + s, m, V, S.slot[W::group_id()], S.out + 8 * k);
+        TrfResult r = bazin_fit_band<W, TrfView<5>>(L.bt + s, L.bf + s, L.be + s, m, V, S.slot[W::group_id()], S.keys + s, S.out + 8 * k);
         if (st && W::lane() == 0) { st[2 * k] = r.status; st[2 * k + 1] = r.nfev; }
         W::sync();
     }

@@ -341,7 +341,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* s
     W::sync();
     double scale = qnan();
     if (nnz > 0) {
-        wave_rank_select<W>(S.r, n, (nnz - 1) / 2, nnz / 2, S.slot);
+        wave_rank_select<W>(S.r, n, (nnz - 1) / 2, nnz / 2, S.slot, reinterpret_cast<unsigned long long*>(S.alpha));
         scale = ((nnz & 1) ? S.slot[0] : (S.slot[0] + S.slot[1]) / 2.0);
         W::sync();
     }

@@ -57,21 +57,29 @@ struct BatchView {
 template <int SET, int CAP>
 __global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_tier, double* out,
                                                  int ld, int col0, int32_t* status, int st_ld,
-                                                 int st0, unsigned long long* ticket) {
+                                                 int st0, unsigned long long* ticket, int chunk) {
     __shared__ SetLds<SET, CAP> ws;
     __shared__ long long next_obj;
     using W = WaveDev;
     const int ncol = set_ncols(SET);
     const int nst = set_nstatus(SET);
-    int64_t i = blockIdx.x;
-    for (;; i += gridDim.x) {
-        if (ticket) {
-            if (threadIdx.x == 0) next_obj = (long long)atomicAdd(ticket, 1ull);
-            __syncthreads();
-            i = next_obj;
-            __syncthreads();
+    // one ticket = `chunk` consecutive objects (a single shared counter saturates near 90 tickets/us,
+    // so the cheap streaming sets take 8 objects per ticket; the fits take one)
+    int64_t base = (int64_t)blockIdx.x * chunk, i = base - 1;
+    for (;;) {
+        ++i;
+        if (i >= base + chunk || i >= B.n_obj) {
+            if (ticket) {
+                if (threadIdx.x == 0) next_obj = (long long)atomicAdd(ticket, 1ull);
+                __syncthreads();
+                base = next_obj * chunk;
+                __syncthreads();
+            } else {
+                base += (int64_t)gridDim.x * chunk;
+            }
+            i = base;
+            if (i >= B.n_obj) break;
         }
-        if (i >= B.n_obj) break;
         const int64_t s = B.offsets[i];
         const int64_t n64 = B.offsets[i + 1] - s;
         if (n64 <= lo) continue;
@@ -195,9 +203,15 @@ int launch_tier(const BatchView& B, int lo, int last, double* out, int ld, int c
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    if (ticket) HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), stream));
+    const int chunk = (SET == SET_BAZIN || SET == SET_POWERLAW) ? 1 : 8;
+    if (grid * chunk > B.n_obj) grid = (B.n_obj + chunk - 1) / chunk;
+    if (ticket) {
+        // tickets 0..grid-1 are taken implicitly by the blocks' first chunk
+        HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ticket, (int)grid, 1, stream));
+    }
     hipLaunchKernelGGL((set_kernel<SET, CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, lo, last, out,
-                       ld, col0, status, st_ld, st0, ticket);
+                       ld, col0, status, st_ld, st0, ticket, chunk);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -12,6 +12,7 @@ template <int CAP>
 struct PhysicsLds {
     double xs[CAP];
     double ys[CAP];
+    unsigned long long keys[CAP];
     double slot[2];
     double out[PHYSICS_NCOL];
 };
@@ -234,7 +235,7 @@ LCFE_FN void physics_object(const ObjLds<CAP>& L, double z_in, PhysicsLds<CAP>& 
         double s = 0;
         for (int i = lane; i < cnt; i += W::LANES) s += S.xs[i];
         msnr = W::sum(s) / cnt;
-        medsnr = wave_median<W>(S.xs, cnt, S.slot);
+        medsnr = wave_median<W>(S.xs, cnt, S.slot, S.keys);
         double mf, vf, lo, hi;
         wave_moments<W>(S.ys, cnt, mf, vf, lo, hi);
         double se2 = 0;

@@ -13,7 +13,9 @@ template <int CAP>
 struct ShapeLds {
     double xs[CAP];
     double ys[CAP];
+    unsigned long long keys[CAP];
     double sel[8];
+    double pkt[6], pkn[6];       // per-band peak time / "band has >= 3 points"
     double out[SHAPE_NCOL + 1];
 };
 
@@ -76,8 +78,8 @@ LCFE_FN double shape_duration_above(const double* t, const double* f, int n, dou
 }
 
 // lightcurve_shape.py:107-144 -> (alpha, rms residual)
-template <class W, int CAP>
-LCFE_FN void shape_power_law(const double* t, const double* f, int n, double pt, double pf, ShapeLds<CAP>& S,
+template <class W>
+LCFE_FN void shape_power_law(const double* t, const double* f, int n, double pt, double pf, double* xs, double* ys,
                              double& alpha, double& resid) {
     alpha = qnan();
     resid = qnan();
@@ -88,14 +90,14 @@ LCFE_FN void shape_power_law(const double* t, const double* f, int n, double pt,
         const bool ok = (i < n) && (t[i] > pt + 5) && (f[i] > 0);
         double lx = 0, ly = 0;
         if (ok) { lx = log10(fmax(t[i] - pt, 1.0)); ly = log10(fmax(f[i], 1e-10)); }
-        cnt = wave_compact<W>(ok, lx, ly, S.xs, S.ys, cnt);
+        cnt = wave_compact<W>(ok, lx, ly, xs, ys, cnt);
     }
     W::sync();
     if (cnt >= 5) {
         double slope, icpt;
-        wave_linfit<W>(S.xs, S.ys, cnt, slope, icpt);
+        wave_linfit<W>(xs, ys, cnt, slope, icpt);
         double q = 0;
-        for (int i = W::lane(); i < cnt; i += W::LANES) { const double d = S.ys[i] - (slope * S.xs[i] + icpt); q += d * d; }
+        for (int i = W::lane(); i < cnt; i += W::LANES) { const double d = ys[i] - (slope * xs[i] + icpt); q += d * d; }
         q = W::sum(q);
         alpha = slope;
         resid = sqrt(q / cnt);
@@ -106,7 +108,7 @@ LCFE_FN void shape_power_law(const double* t, const double* f, int n, double pt,
 
 // np.percentile(x, q) (linear) of m wave-shared values by rank selection; sel = 2 doubles scratch
 template <class W>
-LCFE_FN double wave_percentile(const double* x, int m, double q, double* sel) {
+LCFE_FN double wave_percentile(const double* x, int m, double q, double* sel, unsigned long long* keys) {
     const double quant = q / 100.0;
     const double vi = m * quant + (1.0 - quant) - 1.0;      // numpy _compute_virtual_index, alpha = beta = 1
     int lo = (int)floor(vi);
@@ -115,58 +117,54 @@ LCFE_FN double wave_percentile(const double* x, int m, double q, double* sel) {
     hi = hi < 0 ? 0 : (hi > m - 1 ? m - 1 : hi);
     const double gamma = vi - floor(vi);
     bool nanf = false;
-    for (int i = W::lane(); i < m; i += W::LANES) {
-        const double xi = x[i];
-        nanf = nanf || is_nan(xi);
-        const uint64_t ki = sort_key(xi);
-        int clt = 0, cle = 0;
-        for (int j = 0; j < m; ++j) {
-            const uint64_t kj = sort_key(x[j]);
-            clt += (kj < ki);
-            cle += (kj <= ki);
-        }
-        if (clt <= lo && lo < cle) sel[0] = xi;
-        if (clt <= hi && hi < cle) sel[1] = xi;
+    for (int i = W::lane(); i < m; i += W::LANES) nanf = nanf || is_nan(x[i]);
+    {
+        const int ranks[2] = {lo, hi};
+        wave_select_ranks<W, 2>(x, m, keys, ranks, sel);
     }
-    W::sync();
     const double r = np_lerp(sel[0], sel[1], gamma);
     const bool any_nan = W::any(nanf);
     W::sync();
     return any_nan ? qnan() : r;
 }
 
-template <class W, int CAP>
+// WG: policy of one per-band pass (8-lane groups on the device: six bands side by side); W: whole wave
+template <class W, class WG, int CAP>
 LCFE_FN void shape_object(const ObjLds<CAP>& L, ShapeLds<CAP>& S) {
     const int lane = W::lane();
     double* o = S.out;
-    double peak_t[6];
-    int npk = 0;
-    for (int k = 0; k < 6; ++k) {                               // lightcurve_shape.py:204-247
+    for (int k = WG::group_id(); k < 6; k += WG::NGROUPS) {     // lightcurve_shape.py:204-247
         const int s = L.boff[k], n = L.boff[k + 1] - s;
         double v[8];
         for (int j = 0; j < 8; ++j) v[j] = qnan();
+        double pkt = qnan();
         if (n >= 3) {
             const double* t = L.bt + s;
             const double* f = L.bf + s;
-            const int pk = wave_argmax_first<W>(f, n);
+            const int pk = wave_argmax_first<WG>(f, n);
             const double pt = t[pk], pf = f[pk];
-            peak_t[npk++] = pt;
-            v[0] = shape_rise_time<W>(t, f, n, pt, pf);
-            v[1] = shape_fade_time<W>(t, f, n, pt, pf, 0.5);
-            v[2] = shape_fade_time<W>(t, f, n, pt, pf, 0.25);
+            pkt = pt;
+            v[0] = shape_rise_time<WG>(t, f, n, pt, pf);
+            v[1] = shape_fade_time<WG>(t, f, n, pt, pf, 0.5);
+            v[2] = shape_fade_time<WG>(t, f, n, pt, pf, 0.25);
             v[3] = (!is_nan(v[0]) && !is_nan(v[1]) && v[1] > 0) ? v[0] / v[1] : qnan();
-            v[4] = shape_duration_above<W>(t, f, n, pf, 0.5);   // np.max(fluxes) == pf (NaN propagates)
-            v[5] = shape_duration_above<W>(t, f, n, pf, 0.25);
-            shape_power_law<W, CAP>(t, f, n, pt, pf, S, v[6], v[7]);
+            v[4] = shape_duration_above<WG>(t, f, n, pf, 0.5);  // np.max(fluxes) == pf (NaN propagates)
+            v[5] = shape_duration_above<WG>(t, f, n, pf, 0.25);
+            shape_power_law<WG>(t, f, n, pt, pf, S.xs + s, S.ys + s, v[6], v[7]);
         }
-        if (lane == 0) for (int j = 0; j < 8; ++j) o[8 * k + j] = v[j];
-        W::sync();
+        if (WG::lane() == 0) {
+            for (int j = 0; j < 8; ++j) o[8 * k + j] = v[j];
+            S.pkt[k] = pkt;                                      // NaN marks "band has < 3 points"
+            S.pkn[k] = (n >= 3) ? 1.0 : 0.0;
+        }
+        WG::sync();
     }
+    W::sync();
     if (lane == 0) {
         // :252-258 peak-time spread over the bands that have >= 3 points
         double vp[6];
         int n = 0;
-        for (int i = 0; i < npk; ++i) if (!is_nan(peak_t[i])) vp[n++] = peak_t[i];
+        for (int k = 0; k < 6; ++k) if (S.pkn[k] != 0.0 && !is_nan(S.pkt[k])) vp[n++] = S.pkt[k];
         if (n >= 2) {
             double lo = vp[0], hi = vp[0], m, sd;
             for (int i = 1; i < n; ++i) { lo = fmin(lo, vp[i]); hi = fmax(hi, vp[i]); }
@@ -198,11 +196,11 @@ LCFE_FN void shape_object(const ObjLds<CAP>& L, ShapeLds<CAP>& S) {
         v[0] = shape_rise_time<W>(L.t, L.f, n, pt, pf);
         v[1] = shape_fade_time<W>(L.t, L.f, n, pt, pf, 0.5);
         v[2] = (!is_nan(v[0]) && !is_nan(v[1]) && v[1] > 0) ? v[0] / v[1] : qnan();
-        shape_power_law<W, CAP>(L.t, L.f, n, pt, pf, S, v[3], v[4]);
-        v[5] = wave_percentile<W>(L.f, n, 10.0, S.sel);
-        v[6] = wave_percentile<W>(L.f, n, 25.0, S.sel);
-        v[7] = wave_percentile<W>(L.f, n, 75.0, S.sel);
-        v[8] = wave_percentile<W>(L.f, n, 90.0, S.sel);
+        shape_power_law<W>(L.t, L.f, n, pt, pf, S.xs, S.ys, v[3], v[4]);
+        v[5] = wave_percentile<W>(L.f, n, 10.0, S.sel, S.keys);
+        v[6] = wave_percentile<W>(L.f, n, 25.0, S.sel, S.keys);
+        v[7] = wave_percentile<W>(L.f, n, 75.0, S.sel, S.keys);
+        v[8] = wave_percentile<W>(L.f, n, 90.0, S.sel, S.keys);
         double sum = 0;
         for (int i = lane; i < n; i += W::LANES) sum += L.f[i];
         sum = W::sum(sum);

@@ -98,6 +98,53 @@ LCFE_FN void stage_object(const ObjIn& in, ObjLds<CAP>& L) {
     W::sync();
 }
 
+// Order statistics by rank counting.  `x` = m wave-shared values, `keys` = m words of wave-shared
+// scratch.  For every requested rank r (0-based position in numpy's sort order, NaN last) the value
+// whose [count_less, count_less_or_equal) interval contains r is written to sel[t] -- equal values
+// share an interval, so ties need no index tie-break.  The scan is register-blocked (4 own
+// elements per lane against 4 keys per trip) so that LDS reads are pipelined instead of exposing
+// one round trip per comparison.
+template <class W, int NT>
+LCFE_FN void wave_select_ranks(const double* x, int m, unsigned long long* keys, const int* ranks, double* sel) {
+    const int lane = W::lane();
+    for (int i = lane; i < m; i += W::LANES) keys[i] = sort_key(x[i]);
+    W::sync();
+    const int m4 = m & ~3;
+    for (int base = 0; base < m; base += 4 * W::LANES) {
+        unsigned long long ki[4];
+        int clt[4] = {0, 0, 0, 0}, cle[4] = {0, 0, 0, 0};
+        bool own[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = base + c * W::LANES + lane;
+            own[c] = i < m;
+            ki[c] = own[c] ? keys[i] : 0ull;
+        }
+        for (int j = 0; j < m4; j += 4) {
+            const unsigned long long k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                clt[c] += (k0 < ki[c]) + (k1 < ki[c]) + (k2 < ki[c]) + (k3 < ki[c]);
+                cle[c] += (k0 <= ki[c]) + (k1 <= ki[c]) + (k2 <= ki[c]) + (k3 <= ki[c]);
+            }
+        }
+        for (int j = m4; j < m; ++j) {
+            const unsigned long long kj = keys[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { clt[c] += (kj < ki[c]); cle[c] += (kj <= ki[c]); }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!own[c]) continue;
+            const int i = base + c * W::LANES + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (clt[c] <= ranks[t] && ranks[t] < cle[c]) sel[t] = x[i];
+        }
+    }
+    W::sync();
+}
+
 // numpy.argmax semantics on a (wave-shared) array: index of the FIRST maximum; a NaN counts as
 // the maximum (numpy propagates the first NaN).  Returns -1 for m == 0.  Uniform result.
 template <class W>

@@ -28,7 +28,7 @@ LCFE_FN double np_lerp(double a, double b, double t) {
 // `dev` m doubles of wave-shared scratch.  out17 is wave-shared; lane 0 writes it.
 template <class W>
 LCFE_FN void group_statistics(const double* gt, const double* gf, const double* ge, int m,
-                              bool time_sorted, double* sel, double* dev, double* out17) {
+                              bool time_sorted, double* sel, double* dev, unsigned long long* keys, double* out17) {
     const int lane = W::lane();
     if (m == 0) {                                    // statistical.py:56-66
         if (lane == 0) {
@@ -100,23 +100,10 @@ LCFE_FN void group_statistics(const double* gt, const double* gf, const double* 
     const double v25 = 0.25 * (m - 1), v75 = 0.75 * (m - 1);
     const int r25 = (int)floor(v25), r75 = (int)floor(v75);
     const int r25h = (r25 + 1 < m) ? r25 + 1 : m - 1, r75h = (r75 + 1 < m) ? r75 + 1 : m - 1;
-    for (int i = lane; i < m; i += W::LANES) {
-        const uint64_t ki = sort_key(gf[i]);
-        int clt = 0, cle = 0;
-        for (int j = 0; j < m; ++j) {
-            const uint64_t kj = sort_key(gf[j]);
-            clt += (kj < ki);
-            cle += (kj <= ki);
-        }
-        const double x = gf[i];
-        if (clt <= r_med_lo && r_med_lo < cle) sel[0] = x;
-        if (clt <= r_med_hi && r_med_hi < cle) sel[1] = x;
-        if (clt <= r25 && r25 < cle) sel[2] = x;
-        if (clt <= r25h && r25h < cle) sel[3] = x;
-        if (clt <= r75 && r75 < cle) sel[4] = x;
-        if (clt <= r75h && r75h < cle) sel[5] = x;
+    {
+        const int ranks[6] = {r_med_lo, r_med_hi, r25, r25h, r75, r75h};
+        wave_select_ranks<W, 6>(gf, m, keys, ranks, sel);
     }
-    W::sync();
     // np.median: mean of the two middle elements; NaN anywhere -> NaN
     double med = (r_med_lo == r_med_hi) ? sel[0] : (sel[0] + sel[1]) / 2.0;
     double iqr = 0.0;
@@ -130,18 +117,10 @@ LCFE_FN void group_statistics(const double* gt, const double* gf, const double* 
     // ---- MAD = median(|x - med|)
     for (int i = lane; i < m; i += W::LANES) dev[i] = fabs(gf[i] - med);
     W::sync();
-    for (int i = lane; i < m; i += W::LANES) {
-        const uint64_t ki = sort_key(dev[i]);
-        int clt = 0, cle = 0;
-        for (int j = 0; j < m; ++j) {
-            const uint64_t kj = sort_key(dev[j]);
-            clt += (kj < ki);
-            cle += (kj <= ki);
-        }
-        if (clt <= r_med_lo && r_med_lo < cle) sel[6] = dev[i];
-        if (clt <= r_med_hi && r_med_hi < cle) sel[7] = dev[i];
+    {
+        const int ranks[2] = {r_med_lo, r_med_hi};
+        wave_select_ranks<W, 2>(dev, m, keys, ranks, sel + 6);
     }
-    W::sync();
     double mad = (r_med_lo == r_med_hi) ? sel[6] : (sel[6] + sel[7]) / 2.0;
     if (W::any(nanf)) mad = qnan();
     // ---- max slope between time-consecutive rows (statistical.py:99-113)
@@ -200,20 +179,25 @@ LCFE_FN void group_statistics(const double* gt, const double* gf, const double* 
 template <int CAP>
 struct StatScratch {
     double dev[CAP];
-    double sel[8];
+    unsigned long long keys[CAP];
+    double sel[8][8];            // one row per lane group
     double out[STAT_NCOL + 5];
 };
 
 // All 123 columns of one staged object into S.out (wave-shared).
-template <class W, int CAP>
+// WG: policy of one per-band pass (on the device the six bands run side by side in 8-lane groups of
+// the wave); W: policy of the whole wave (the all-rows pass and the cross-band epilogue).
+template <class W, class WG, int CAP>
 LCFE_FN void stat_object(const ObjLds<CAP>& L, StatScratch<CAP>& S) {
     const int lane = W::lane();
-    for (int k = 0; k < 6; ++k) {
+    for (int k = WG::group_id(); k < 6; k += WG::NGROUPS) {
         const int s = L.boff[k], m = L.boff[k + 1] - s;
-        group_statistics<W>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel, S.dev, S.out + 17 * k);
-        W::sync();
+        group_statistics<WG>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel[WG::group_id()], S.dev + s, S.keys + s,
+                             S.out + 17 * k);
+        WG::sync();
     }
-    group_statistics<W>(L.t, L.f, L.e, L.n, L.sorted != 0, S.sel, S.dev, S.out + 102);
+    W::sync();
+    group_statistics<W>(L.t, L.f, L.e, L.n, L.sorted != 0, S.sel[0], S.dev, S.keys, S.out + 102);
     W::sync();
     if (lane == 0) {
         double* o = S.out;

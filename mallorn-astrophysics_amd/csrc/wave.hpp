@@ -43,37 +43,39 @@ struct WaveDev {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    static __device__ __forceinline__ double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
-    static __device__ __forceinline__ double sum(double v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        return v;
+    // Reductions: four DPP steps leave every lane with the total of its 16-lane row (quad swaps,
+    // row_half_mirror, row_mirror -- register moves, no LDS crossbar), then the four row totals are
+    // read with v_readlane and combined; the result is wave-uniform.
+    template <int CTRL>
+    static __device__ __forceinline__ double dpp(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)b, hi = (int)(b >> 32);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
-    static __device__ __forceinline__ double max(double v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
-        return v;
+    template <int CTRL>
+    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+    static __device__ __forceinline__ double rdlane(double v, int l) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
-    static __device__ __forceinline__ double min(double v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = (o < v) ? o : v; }
-        return v;
+    static __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+    template <class V, class Op>
+    static __device__ __forceinline__ V reduce(V v, Op op) {
+        v = op(v, dpp<0xB1>(v));      // quad_perm(1,0,3,2)
+        v = op(v, dpp<0x4E>(v));      // quad_perm(2,3,0,1)
+        v = op(v, dpp<0x141>(v));     // row_half_mirror
+        v = op(v, dpp<0x140>(v));     // row_mirror
+        return op(op(rdlane(v, 0), rdlane(v, 16)), op(rdlane(v, 32), rdlane(v, 48)));
     }
-    static __device__ __forceinline__ int sum(int v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        return v;
-    }
-    static __device__ __forceinline__ int max(int v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
-        return v;
-    }
-    static __device__ __forceinline__ int min(int v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = (o < v) ? o : v; }
-        return v;
-    }
+    static __device__ __forceinline__ double sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+    static __device__ __forceinline__ double max(double v) { return reduce(v, [](double a, double b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ double min(double v) { return reduce(v, [](double a, double b) { return (b < a) ? b : a; }); }
+    static __device__ __forceinline__ int sum(int v) { return reduce(v, [](int a, int b) { return a + b; }); }
+    static __device__ __forceinline__ int max(int v) { return reduce(v, [](int a, int b) { return (b > a) ? b : a; }); }
+    static __device__ __forceinline__ int min(int v) { return reduce(v, [](int a, int b) { return (b < a) ? b : a; }); }
     static __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
     static __device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0ull; }
     static __device__ __forceinline__ bool all(bool p) { return __ballot(!p) == 0ull; }
@@ -134,6 +136,13 @@ struct GroupDev {
     static __device__ __forceinline__ int min(int v) { return reduce(v, [](int a, int b) { return (b < a) ? b : a; }); }
     static __device__ __forceinline__ bool any(bool p) { return max(p ? 1 : 0) != 0; }
     static __device__ __forceinline__ bool all(bool p) { return min(p ? 1 : 0) != 0; }
+    // ballot over the lanes of this group only (the other groups of the wave may be elsewhere)
+    static __device__ __forceinline__ unsigned long long ballot(bool p) {
+        return (__ballot(p) >> (group_id() * GS)) & ((1ull << GS) - 1);
+    }
+    static __device__ __forceinline__ int prefix(unsigned long long mask) {
+        return __builtin_popcountll(mask & ((1ull << lane()) - 1));
+    }
 };
 
 // A workgroup of T threads (T/64 wavefronts) working on one object: the GP kernel's policy.
