@@ -29,8 +29,9 @@ template <class P> struct gp_is_lds_ptr { static constexpr bool value = false; }
 template <> struct gp_is_lds_ptr<lds_double*> { static constexpr bool value = true; };
 #endif
 
-// pivot-block width of the sweep (16 was measured for the global-scratch tiers: no gain, the
-// update is latency- not bandwidth-bound there)
+// pivot-block width of the sweep.  16 was measured twice for the global-scratch tier (1284 ms vs
+// 1093 ms for the 20k-object batch): no gain -- that tier is bound by per-element latency and
+// instruction issue, not by the number of passes over the L2/MALL-resident matrix.
 template <int NP> struct gp_block { static constexpr int B = 8; };
 
 // Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
@@ -40,11 +41,12 @@ struct GpLds {
     double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
     double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
     double V[gp_block<NP>::B][NP];            // pivot-block columns A(:, P)
-    double P[NW][gp_block<NP>::B][gp_block<NP>::B];  // per-wavefront copy of the pivot block -> minus its inverse
+    double P[(NW <= 4) ? NW : 1][gp_block<NP>::B][gp_block<NP>::B];  // per-wavefront copy (one shared copy for > 4 waves) of the pivot block -> minus its inverse
     double Wm[gp_block<NP>::B][NP];           // A(:, P) * A(P,P)^-1
     double lb_s[10][4], lb_y[10][4], lb_rho[10];   // L-BFGS memory (block-uniform, kept out of registers)
     double slot[2];
     double out[GP_NCOL + 1];
+    int pivot_bad;                            // shared-copy mode: wave 0 reports a non-positive pivot
 #ifdef LCFE_GP_PROF
     unsigned long long prof[12];
 #endif
@@ -80,9 +82,10 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
     constexpr int G0 = (NP <= 64) ? 16 : ((NP <= 128) ? 32 : 64);
     constexpr int G = (W::LANES >= G0) ? G0 : W::LANES;
     constexpr int RG = W::LANES / G;                        // rows in flight
-    constexpr int U = 2;                                    // independent elements per lane and trip
+    constexpr int U = (B == 16) ? 1 : 2;                    // independent elements per lane and trip
     const int rl = lane / G, cl = lane % G;
-    double (*Pw)[B] = S.P[W::wave_id()];
+    constexpr bool PER_WAVE = (W::NWAVES <= 4);             // else: wave 0 inverts one shared copy
+    double (*Pw)[B] = S.P[PER_WAVE ? W::wave_id() : 0];
     double ld = 0.0;
     for (int k0 = 0; k0 < n; k0 += B) {
         const int bs = (n - k0 < B) ? n - k0 : B;
@@ -95,42 +98,54 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
                 S.V[p][i] = (p < bs) ? ((i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)]) : 0.0;
             }
         }
+        if (!PER_WAVE && lane == 0) S.pivot_bad = 0;
         W::sync();
         GP_T(0);
-        // (2) every wavefront inverts its own copy of the (identity-padded) pivot block by B
-        //     single-index sweeps: only wave-level hand-offs, no workgroup barrier
-        for (int e = W::wlane(); e < B * B; e += W::WAVE) {
-            const int a = e / B, b = e % B;
-            Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
-        }
-        W::wave_sync();
-        double prod = 1.0;
-        for (int q = 0; q < B; ++q) {
-            const double d = Pw[q][q];
-            if (!(d > 0.0)) return false;                   // identical in every wavefront -> uniform
-            prod *= d;
-            if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }      // one log per 8 pivots (no overflow)
-            const double inv = 1.0 / d;
-            constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
-            double nv[NV];
-#pragma unroll
-            for (int c = 0; c < NV; ++c) {
-                const int e = W::wlane() + c * W::WAVE;
+        // (2) inversion of the (identity-padded) pivot block by B single-index sweeps with only
+        //     wave-level hand-offs: every wavefront on its own copy, or wave 0 on a shared one
+        bool bad = false;
+        if (PER_WAVE || W::wave_id() == 0) {
+            for (int e = W::wlane(); e < B * B; e += W::WAVE) {
                 const int a = e / B, b = e % B;
-                const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
-                double v = pab - paq * pqb * inv;
-                if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
-                if (a == q && b == q) v = -inv;
-                nv[c] = v;
+                Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
             }
             W::wave_sync();
+            double prod = 1.0;
+            for (int q = 0; q < B; ++q) {
+                const double d = Pw[q][q];
+                if (!(d > 0.0)) bad = true;                     // identical in every wavefront -> uniform
+                prod *= d;
+                if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }      // one log per 8 pivots (no overflow)
+                const double inv = 1.0 / d;
+                constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
+                double nv[NV];
 #pragma unroll
-            for (int c = 0; c < NV; ++c) {
-                const int e = W::wlane() + c * W::WAVE;
-                Pw[e / B][e % B] = nv[c];
+                for (int c = 0; c < NV; ++c) {
+                    const int e = W::wlane() + c * W::WAVE;
+                    const int a = e / B, b = e % B;
+                    const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
+                    double v = pab - paq * pqb * inv;
+                    if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
+                    if (a == q && b == q) v = -inv;
+                    nv[c] = v;
+                }
+                W::wave_sync();
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const int e = W::wlane() + c * W::WAVE;
+                    Pw[e / B][e % B] = nv[c];
+                }
+                W::wave_sync();
             }
-            W::wave_sync();
+            if (!PER_WAVE && bad && W::wlane() == 0) S.pivot_bad = 1;
         }
+        if (!PER_WAVE) {
+            W::sync();
+            bad = (S.pivot_bad != 0);
+            // log-determinant: only wave 0 accumulated it; every lane needs the same value
+            ld = W::bcast_from_first_wave(ld);
+        }
+        if (bad) return false;
         GP_T(1);
         // now Pw = -A_PP^-1 (padding: -1 on the diagonal, met only by zero rows of V)
         // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw): one matrix row per lane
@@ -294,8 +309,10 @@ LCFE_FN bool gp_row_valid(const ObjIn& in, int i) {
 
 // multiband_gp.py:292-344 for one object (rows read straight from the CSR slice, file order).
 // `K` points to packed-triangle storage for NP points (LDS or global scratch).
-template <class W, int NP, class KP>
-LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* st) {
+// `ev(p, n, f, g, need_grad)` evaluates the objective (gp_eval with the matrix in LDS / global
+// scratch, or gp_eval_reg with the matrix in registers).
+template <class W, int NP, class Ev>
+LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, Ev&& gp_ev, int32_t* st) {
     const int lane = W::lane();
     double* o = S.out;
     for (int k = lane; k < GP_NCOL; k += W::LANES) o[k] = qnan();
@@ -310,7 +327,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* s
         n += gp_row_valid(L, i) ? 1 : 0;
     }
     n = W::sum(n);
-    if (n >= 10 && n <= NP) {
+    if (n >= 10 && n + 1 <= NP) {
         for (int i = lane; i < L.n; i += W::LANES) {
             if (!gp_row_valid(L, i)) continue;
             int pos = 0;
@@ -325,7 +342,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* s
     W::sync();
     if (st && lane == 0) { st[0] = 0; st[1] = 0; st[2] = 0; st[3] = n; }
     if (n < 10) { W::sync(); return; }                                  // :66 -> all 27 NaN
-    if (n > NP) { if (st && lane == 0) st[0] = -100; W::sync(); return; }
+    if (n + 1 > NP) { if (st && lane == 0) st[0] = -100; W::sync(); return; }   // + the augmented row of gp_eval_reg
     double tmin = __builtin_inf();
     int nnz = 0;
     for (int i = lane; i < n; i += W::LANES) { tmin = fmin(tmin, S.t[i]); }
@@ -365,7 +382,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* s
     double fval = 0;
     int n_iter = 0, n_eval = 0, why = LB_ERROR;
     if (finite0) {
-        auto ev = [&](const double* x, double& f, double* g) { gp_eval<W, NP, KP>(x, n, S, K, f, g, true); };
+        auto ev = [&](const double* x, double& f, double* g) { gp_ev(x, n, f, g, true); };
         why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval, S.lb_s, S.lb_y, S.lb_rho);
     }
     if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
@@ -402,7 +419,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, KP K, int32_t* s
     const double peak_time = L.t[pk] - tmin_all;
     // ---- interpolate_multiband (:196-289): alpha at the optimum, then 12 predictions
     double ftmp, gtmp[4];
-    gp_eval<W, NP, KP>(p, n, S, K, ftmp, gtmp, false);
+    gp_ev(p, n, ftmp, gtmp, false);
     if (ftmp >= 1e25) { W::sync(); return; }          // factorisation failed at the optimum: predict raises -> NaN (:279-287)
     const double c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
     const double EP[4] = {0, 20, 50, 100};

@@ -185,6 +185,15 @@ struct BlockDev {
     static __device__ __forceinline__ int min(int v) { return reduce(v, [](int a, int b) { return (b < a) ? b : a; }); }
     static __device__ __forceinline__ bool any(bool p) { return sum(p ? 1 : 0) != 0; }
     static __device__ __forceinline__ bool all(bool p) { return sum(p ? 0 : 1) == 0; }
+    // value held (uniformly) by wavefront 0 -> every thread of the workgroup
+    static __device__ __forceinline__ double bcast_from_first_wave(double v) {
+        __shared__ double slot;
+        if (threadIdx.x == 0) slot = v;
+        __syncthreads();
+        const double r = slot;
+        __syncthreads();
+        return r;
+    }
 };
 #endif
 
@@ -211,6 +220,7 @@ struct WaveHost {
     static int prefix(unsigned long long) { return 0; }
     static double bcast(double v, int) { return v; }
     static int bcast(int v, int) { return v; }
+    static double bcast_from_first_wave(double v) { return v; }
 };
 
 LCFE_FN int popcll(unsigned long long m) { return __builtin_popcountll(m); }

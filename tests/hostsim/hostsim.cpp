@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../mallorn-astrophysics_amd/csrc/feature_sets.hpp"
+#include "../../mallorn-astrophysics_amd/csrc/gp_reg.hpp"
 
 using namespace lcfe;
 
@@ -55,8 +56,16 @@ static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const
         ObjIn in{t + s, flux + s, err + s, band + s, n, qnan()};
         int32_t* st = status ? status + set_nstatus(SET_GP2D) * i : nullptr;
         const double* o;
-        if (n <= NS) { gp_object<W, NS, double*>(in, *ws, K.data(), st); o = ws->out; }
-        else { gp_object<W, NL, double*>(in, *wl, K.data(), st); o = wl->out; }
+        // short light curves: register-tiled evaluation (one-lane grid: TS = 1); long: packed-matrix sweep
+        if (n + 1 <= NS) {
+            gp_object<W, NS>(in, *ws, [&](const double* x, int nn, double& f, double* g, bool need) {
+                gp_eval_reg<W, NS, 1, NS>(x, nn, *ws, f, g, need); }, st);
+            o = ws->out;
+        } else {
+            gp_object<W, NL>(in, *wl, [&](const double* x, int nn, double& f, double* g, bool need) {
+                gp_eval<W, NL, double*>(x, nn, *wl, K.data(), f, g, need); }, st);
+            o = wl->out;
+        }
         for (int k = 0; k < GP_NCOL; ++k) out[i * GP_NCOL + k] = o[k];
     }
 }
