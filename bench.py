@@ -172,6 +172,12 @@ def main():
     rk = "stat" if "stat" in sets else max(per_set, key=per_set.get)
     alg_bytes = 25 * n_pts + 8 * (a.objects + 1) + 8 * a.objects * NCOLS[rk] + (8 * a.objects if rk == "physics" else 0)
     achieved = alg_bytes / (per_set[rk] * 1e-3) / 1e9 if per_set[rk] > 0 else 0.0
+    # HBM traffic of the roofline kernel from PMC counters (collected offline in separate rocprofv3
+    # --pmc passes on this exact workload; bench.py cannot run under the counters itself)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_stat_traffic.json")
+    if rk == "stat" and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
+        traffic = json.load(open(tj)).get("hbm_bytes_per_pass")
     res = {
         "metric": "light curves/sec", "value": a.objects * world * a.steps / dt, "unit": "light curves/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -182,7 +188,7 @@ def main():
                    "one RCCL gather of the feature rows per step" if world > 1 else "single GPU"},
         "kernel_ms": per_set,
         "roofline": {"kernel": f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": per_set[rk]},
     }
     if not a.no_cpu_baseline:
