@@ -18,7 +18,13 @@ constexpr int GP_NCOL = 27;
 constexpr double GP_TINY = 1.25e-12;                        // george.gp.TINY (white noise floor)
 constexpr double GP_LOG_2PI = 1.8378770664093453;
 
-LCFE_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; }      // j <= i
+// Storage of the symmetric matrix: lower-triangular 16 x 16 TILES, each tile row-major and
+// contiguous (2 KiB), tiles ordered (ti, tj <= ti) row by row.  Diagonal tiles keep their (unused)
+// upper half.  This is the layout v_mfma_f64_16x16x4_f64 reads and writes with conflict-free
+// 512-byte LDS accesses, and a tile is one coalesced 2 KiB piece of global scratch.
+LCFE_HD int tile_base(int ti, int tj) { return (ti * (ti + 1) / 2 + tj) * 256; }            // tj <= ti
+LCFE_HD int tri_index(int i, int j) { return tile_base(i >> 4, j >> 4) + ((i & 15) << 4) + (j & 15); }   // j <= i
+LCFE_HD constexpr int gp_store_doubles(int np) { return ((np + 15) / 16) * ((np + 15) / 16 + 1) / 2 * 256; }
 
 #if defined(__HIPCC__)
 typedef __attribute__((address_space(3))) double lds_double;     // LDS-qualified element type: keeps ds_* addressing across calls
@@ -66,6 +72,127 @@ LCFE_FN double gp_wavelength(int band) {
     return w[band];
 }
 
+#if defined(__HIPCC__)
+typedef double gp_v4f64 __attribute__((ext_vector_type(4)));
+#endif
+
+// Rank-8 update of all tiles for one pivot block.  On the GPU each wavefront takes whole tiles and
+// does the 16 x 16 x 8 product with two v_mfma_f64_16x16x4_f64 (operand layout measured on gfx950,
+// tools/mfma_f64_probe.hip: A lane l = (row l%16, k l/16), B lane l = (k l/16, col l%16), D lane l,
+// register v = (row l/16 + 4v, col l%16)); the host simulation uses plain loops.
+template <class W, int NP, class KP>
+LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs) {
+    static_assert(gp_block<NP>::B == 8, "two 16x16x4 MFMAs cover an 8-wide pivot block");
+    const int nt = (n + 15) >> 4;
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64) {
+        const int l = W::wlane();
+        const int lr = l >> 4, lc = l & 15;
+        const int ntile = nt * (nt + 1) / 2;
+        constexpr int UNR = 4;                 // tiles in flight per wavefront (independent register sets)
+        for (int t0 = W::wave_id() * UNR; t0 < ntile; t0 += W::NWAVES * UNR) {
+            int ti[UNR], tj[UNR];
+            bool on[UNR];
+            gp_v4f64 c[UNR];
+            double a0[UNR], a1[UNR], b0[UNR], b1[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int t = t0 + u;
+                on[u] = t < ntile;
+                const int tt = on[u] ? t : 0;
+                int r = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);      // row of the linear tile index
+                while (r * (r + 1) / 2 > tt) --r;
+                while ((r + 1) * (r + 2) / 2 <= tt) ++r;
+                ti[u] = r;
+                tj[u] = tt - r * (r + 1) / 2;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                KP base = A + tile_base(ti[u], tj[u]);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) c[u][v] = base[((lr + 4 * v) << 4) + lc];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ri = (ti[u] << 4) + lc, cj = (tj[u] << 4) + lc;   // operand row / column of this lane
+                a0[u] = -S.Wm[lr][ri]; a1[u] = -S.Wm[4 + lr][ri];
+                b0[u] = S.V[lr][cj]; b1[u] = S.V[4 + lr][cj];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c[u], 0, 0, 0);
+                c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (!on[u]) continue;
+                KP base = A + tile_base(ti[u], tj[u]);
+                const int col = (tj[u] << 4) + lc;
+                const bool col_in = (col >= k0 && col < k0 + bs);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = (ti[u] << 4) + lr + 4 * v;
+                    const bool row_in = (row >= k0 && row < k0 + bs);
+                    if (!col_in && !row_in) base[((lr + 4 * v) << 4) + lc] = c[u][v];
+                }
+            }
+        }
+        return;
+    }
+#endif
+    (void)nt;
+    for (int i = W::lane(); i < n; i += W::LANES) {
+        if (i >= k0 && i < k0 + bs) continue;
+        for (int j = 0; j <= i; ++j) {
+            if (j >= k0 && j < k0 + bs) continue;
+            double acc = 0;
+            for (int p = 0; p < gp_block<NP>::B; ++p) acc = fma(S.Wm[p][i], S.V[p][j], acc);
+            A[tri_index(i, j)] -= acc;
+        }
+    }
+}
+
+// Wm = V^T * (-Pw): 16 rows of the matrix per MFMA pair on the GPU (B operand = the 8 x 8 block
+// padded to 16 columns), one row per lane otherwise.
+template <class W, int NP>
+LCFE_FN void gp_row_weights(GpLds<NP, W::NWAVES>& S, const double (*Pw)[gp_block<NP>::B], int n) {
+    constexpr int B = gp_block<NP>::B;
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64) {
+        const int l = W::wlane();
+        const int lr = l >> 4, lc = l & 15;
+        // B operand: (k = lr [+4], col = lc): -Pw[k][col] for col < 8, zero padding beyond
+        const double b0 = (lc < B) ? -Pw[lr][lc] : 0.0, b1 = (lc < B) ? -Pw[4 + lr][lc] : 0.0;
+        const int nt = (n + 15) >> 4;
+        for (int t = W::wave_id(); t < nt; t += W::NWAVES) {
+            const int ri = (t << 4) + lc;
+            const double a0 = S.V[lr][ri], a1 = S.V[4 + lr][ri];          // A operand: (row = lc, k = lr [+4])
+            gp_v4f64 c = {0, 0, 0, 0};
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+            // D lane (row = lr + 4v, col = lc): Wm[col][row]
+            if (lc < B) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) S.Wm[lc][(t << 4) + lr + 4 * v] = c[v];
+            }
+        }
+        return;
+    }
+#endif
+    for (int i = W::lane(); i < n; i += W::LANES) {
+        double vq[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) vq[q] = S.V[q][i];
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+            double sacc = 0;
+#pragma unroll
+            for (int q = 0; q < B; ++q) sacc = fma(-vq[q], Pw[q][p], sacc);
+            S.Wm[p][i] = sacc;
+        }
+    }
+}
+
 // In-place inverse of the packed symmetric positive-definite matrix A (lower triangle, row-major)
 // by a BLOCKED SYMMETRIC SWEEP: for each pivot block P of B consecutive indices
 //     A_PP <- -A_PP^-1 ,  A_RP <- A_RP A_PP^-1 ,  A_RR <- A_RR - A_RP A_PP^-1 A_PR     (R = all other indices)
@@ -78,12 +205,6 @@ template <class W, int NP, class KP>
 LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logdet) {
     constexpr int B = gp_block<NP>::B;
     const int lane = W::lane();
-    // lanes that share one matrix row in the rank-B update: short rows for the small tiers
-    constexpr int G0 = (NP <= 64) ? 16 : ((NP <= 128) ? 32 : 64);
-    constexpr int G = (W::LANES >= G0) ? G0 : W::LANES;
-    constexpr int RG = W::LANES / G;                        // rows in flight
-    constexpr int U = (B == 16) ? 1 : 2;                    // independent elements per lane and trip
-    const int rl = lane / G, cl = lane % G;
     constexpr bool PER_WAVE = (W::NWAVES <= 4);             // else: wave 0 inverts one shared copy
     double (*Pw)[B] = S.P[PER_WAVE ? W::wave_id() : 0];
     double ld = 0.0;
@@ -148,57 +269,13 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
         if (bad) return false;
         GP_T(1);
         // now Pw = -A_PP^-1 (padding: -1 on the diagonal, met only by zero rows of V)
-        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw): one matrix row per lane
-        for (int i = lane; i < n; i += W::LANES) {
-            double vq[B];
-#pragma unroll
-            for (int q = 0; q < B; ++q) vq[q] = S.V[q][i];
-#pragma unroll
-            for (int p = 0; p < B; ++p) {
-                double sacc = 0;
-#pragma unroll
-                for (int q = 0; q < B; ++q) sacc = fma(-vq[q], Pw[q][p], sacc);
-                S.Wm[p][i] = sacc;
-            }
-        }
+        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw)
+        gp_row_weights<W, NP>(S, Pw, n);
         W::sync();
         GP_T(2);
-        // (4) rank-B update of every row outside the pivot block (pivot columns are skipped and
-        //     rewritten in (5))
-        for (int i = rl; i < n; i += RG) {
-            if (i >= k0 && i < k0 + bs) continue;
-            double wi[B];
-#pragma unroll
-            for (int p = 0; p < B; ++p) wi[p] = S.Wm[p][i];
-            KP row = A + tri_index(i, 0);
-            int j = cl;
-            for (; j + (U - 1) * G <= i; j += U * G) {
-                double v[U][B], x[U], acc[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) x[u] = row[j + u * G];
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int p = 0; p < B; ++p) v[u][p] = S.V[p][j + u * G];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    acc[u] = 0;
-#pragma unroll
-                    for (int p = 0; p < B; ++p) acc[u] = fma(wi[p], v[u][p], acc[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int jj = j + u * G;
-                    if (!(jj >= k0 && jj < k0 + bs)) row[jj] = x[u] - acc[u];
-                }
-            }
-            for (; j <= i; j += G) {
-                double a0 = 0;
-#pragma unroll
-                for (int p = 0; p < B; ++p) a0 = fma(wi[p], S.V[p][j], a0);
-                if (!(j >= k0 && j < k0 + bs)) row[j] -= a0;
-            }
-        }
+        // (4) rank-B update of every tile: C -= Wm(rows of the tile) * V(columns of the tile)^T.
+        //     Elements in pivot rows / columns are not stored (they are rewritten in (5)).
+        gp_tile_update<W, NP, KP>(A, n, S, k0, bs);
         // (5) new pivot rows / columns:  A_RP <- A_RP A_PP^-1 ,  A_PP <- -A_PP^-1  (disjoint from (4))
         for (int idx = lane; idx < B * NP; idx += W::LANES) {
             const int p = idx / NP, i = idx - p * NP;
@@ -237,14 +314,13 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     GP_T0();
     // Gram matrix, packed lower
     for (int i = rl; i < n; i += RG) {
-        const int rowi = tri_index(i, 0);
         const double ti = S.t[i], li = S.lam[i];
         for (int j = cl; j <= i; j += G) {
             const double dt = ti - S.t[j], dl = li - S.lam[j];
             double e;
             double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
             if (j == i) k += S.e2[i] + GP_TINY;
-            K[rowi + j] = k;
+            K[tri_index(i, j)] = k;
         }
     }
     for (int i = lane; i < n; i += W::LANES) S.r[i] = S.y[i] - mu;
@@ -258,8 +334,7 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     double ra = 0, sa = 0;
     for (int i = lane; i < n; i += W::LANES) {
         double s = 0;
-        const int rowi = tri_index(i, 0);
-        for (int k = 0; k <= i; ++k) s += K[rowi + k] * S.r[k];
+        for (int k = 0; k <= i; ++k) s += K[tri_index(i, k)] * S.r[k];
         for (int k = i + 1; k < n; ++k) s += K[tri_index(k, i)] * S.r[k];
         s = -s;
         S.alpha[i] = s;
@@ -276,14 +351,13 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta ,  Kinv_ij = -K[ij]
     double g1 = 0, g2 = 0, g3 = 0;
     for (int i = rl; i < n; i += RG) {
-        const int rowi = tri_index(i, 0);
         const double ai = S.alpha[i], ti = S.t[i], li = S.lam[i];
         for (int j = cl; j <= i; j += G) {
             const double dt = ti - S.t[j], dl = li - S.lam[j];
             const double dt2 = dt * dt, dl2 = dl * dl;
             double e;
             const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
-            const double a = (ai * S.alpha[j] + K[rowi + j]) * ((j == i) ? 1.0 : 2.0);
+            const double a = (ai * S.alpha[j] + K[tri_index(i, j)]) * ((j == i) ? 1.0 : 2.0);
             g1 += a * k;
             g2 += a * e * dt2 / m0;
             g3 += a * e * dl2 / m1;

@@ -105,15 +105,15 @@ int num_cus(int dev);
 constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one 1024-thread workgroup per CU
 constexpr int kGpGlobalGrid = 256;
 constexpr size_t kGpMidBytes = 0;
-constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * kGpGlobalNP * (kGpGlobalNP + 1) / 2 * 8;
+constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
 template <int NP, bool GLOBAL_K>
 __global__ __launch_bounds__(GLOBAL_K ? 1024 : 256) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch) {
     using W = BlockDev<(GLOBAL_K ? 1024 : 256)>;
     __shared__ GpLds<NP, W::NWAVES> S;
-    __shared__ double Klds[GLOBAL_K ? 1 : NP * (NP + 1) / 2];
-    double* Kg = kscratch + (size_t)blockIdx.x * ((size_t)NP * (NP + 1) / 2);
+    __shared__ double Klds[GLOBAL_K ? 1 : gp_store_doubles(NP)];
+    double* Kg = kscratch + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
     for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
         const int64_t s = B.offsets[i];
         const int64_t n64 = B.offsets[i + 1] - s;
@@ -210,7 +210,7 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
     // tile passes (1 workgroup per CU) and spills at 1024 threads -- so it is compiled and parity-
     // tested but not scheduled (tiers: reg<16,5> 52 ms / reg<16,8> 164 / reg<16,12> 558 / reg<32,8>
     // 1700 vs LDS<64> 25 / <120> 179 / <176> 386).
-    const int caps[4] = {63, 119, 175, kGpGlobalNP - 1};
+    const int caps[4] = {63, 111, 159, kGpGlobalNP - 1};
     int last = 0;
     while (last < 3 && caps[last] < max_len) ++last;
     if (last >= 3 && kscratch_bytes < kGpMidBytes + kGpGlobalBytes)
@@ -221,15 +221,14 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
         int rc = 0;
         switch (ti) {
             case 0: rc = launch_gp_tier<64, false>(B, lo, caps[0], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 1: rc = launch_gp_tier<120, false>(B, lo, caps[1], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 2: rc = launch_gp_tier<176, false>(B, lo, caps[2], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 1: rc = launch_gp_tier<112, false>(B, lo, caps[1], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
+            case 2: rc = launch_gp_tier<160, false>(B, lo, caps[2], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, caps[3], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
         }
         if (rc) return rc;
         ++*n_launch;
         lo = caps[ti];
     }
-    (void)&launch_gp_reg_tier<16, 8>;     // keeps the register variant compiled (tools/gp_variants)
     return 0;
 }
 

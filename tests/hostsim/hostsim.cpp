@@ -49,15 +49,15 @@ static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const
     constexpr int NS = 176, NL = 768;
     auto ws = std::make_unique<GpLds<NS, 1>>();
     auto wl = std::make_unique<GpLds<NL, 1>>();
-    std::vector<double> K((size_t)NL * (NL + 1) / 2);
+    std::vector<double> K((size_t)gp_store_doubles(NL));
     for (int64_t i = 0; i < n_obj; ++i) {
         const int64_t s = offsets[i];
         const int n = (int)(offsets[i + 1] - s);
         ObjIn in{t + s, flux + s, err + s, band + s, n, qnan()};
         int32_t* st = status ? status + set_nstatus(SET_GP2D) * i : nullptr;
         const double* o;
-        // short light curves: register-tiled evaluation (one-lane grid: TS = 1); long: packed-matrix sweep
-        if (n + 1 <= NS) {
+        // short light curves: register-tiled evaluation (one-lane grid: TS = 1); longer: tiled-matrix sweep
+        if (n + 1 <= 120) {
             gp_object<W, NS>(in, *ws, [&](const double* x, int nn, double& f, double* g, bool need) {
                 gp_eval_reg<W, NS, 1, NS>(x, nn, *ws, f, g, need); }, st);
             o = ws->out;

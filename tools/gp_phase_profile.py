@@ -10,7 +10,7 @@ lc = synth.make_lightcurves(int(sys.argv[1]) if len(sys.argv) > 1 else 4000, see
 out, st = extract_csr("gp2d", lc, return_status=True)
 n = st[:, 3]
 names = ["V gather", "P inverse", "Wm", "update", "gram", "sweep total", "alpha", "grad"]
-for lo, hi in ((0, 64), (64, 120), (120, 176), (176, 800)):
+for lo, hi in ((0, 63), (63, 111), (111, 159), (159, 300), (300, 800)):
     m = (n > lo) & (n <= hi)
     if not m.any():
         continue
