@@ -32,7 +32,7 @@ LCFE_HD int set_nstatus(int set) {
         case SET_BAZIN: return 12;
         case SET_POWERLAW: return 54;
 #ifdef LCFE_GP_PROF
-        case SET_GP2D: return 12;
+        case SET_GP2D: return 16;
 #else
         case SET_GP2D: return 4;
 #endif

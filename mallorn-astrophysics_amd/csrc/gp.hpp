@@ -81,7 +81,7 @@ typedef double gp_v4f64 __attribute__((ext_vector_type(4)));
 // tools/mfma_f64_probe.hip: A lane l = (row l%16, k l/16), B lane l = (k l/16, col l%16), D lane l,
 // register v = (row l/16 + 4v, col l%16)); the host simulation uses plain loops.
 template <class W, int NP, class KP>
-LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs) {
+LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs) {   // n = rows incl. the augmented one
     static_assert(gp_block<NP>::B == 8, "two 16x16x4 MFMAs cover an 8-wide pivot block");
     const int nt = (n + 15) >> 4;
 #if defined(__HIPCC__)
@@ -201,8 +201,12 @@ LCFE_FN void gp_row_weights(GpLds<NP, W::NWAVES>& S, const double (*Pw)[gp_block
 // (george: log-likelihood = -inf).  n/B block steps with two workgroup barriers each; a step is a
 // fully parallel rank-B update of the whole triangle -- this replaces the n sequential columns of
 // a textbook Cholesky + triangular inverse.
+// The matrix carries one extra, never pivoted row n (the residual r = y - mu): the sweep turns it
+// into alpha = K^-1 r and its diagonal into -r'K^-1 r (regression use of the sweep operator), so
+// no solve or matrix-vector product is needed afterwards.
 template <class W, int NP, class KP>
 LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logdet) {
+    const int nrow = n + 1;
     constexpr int B = gp_block<NP>::B;
     const int lane = W::lane();
     constexpr bool PER_WAVE = (W::NWAVES <= 4);             // else: wave 0 inverts one shared copy
@@ -214,7 +218,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
         // (1) V[p][i] = A(i, k0+p) for every i (symmetric access); rows p >= bs are zero padding
         for (int idx = lane; idx < B * NP; idx += W::LANES) {
             const int p = idx / NP, i = idx - p * NP;       // NP is a compile-time constant
-            if (i < n) {
+            if (i < nrow) {
                 const int kp = k0 + p;
                 S.V[p][i] = (p < bs) ? ((i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)]) : 0.0;
             }
@@ -270,16 +274,17 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
         GP_T(1);
         // now Pw = -A_PP^-1 (padding: -1 on the diagonal, met only by zero rows of V)
         // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw)
-        gp_row_weights<W, NP>(S, Pw, n);
+        gp_row_weights<W, NP>(S, Pw, nrow);
         W::sync();
         GP_T(2);
         // (4) rank-B update of every tile: C -= Wm(rows of the tile) * V(columns of the tile)^T.
         //     Elements in pivot rows / columns are not stored (they are rewritten in (5)).
-        gp_tile_update<W, NP, KP>(A, n, S, k0, bs);
+        gp_tile_update<W, NP, KP>(A, nrow, S, k0, bs);
+        GP_T(8);
         // (5) new pivot rows / columns:  A_RP <- A_RP A_PP^-1 ,  A_PP <- -A_PP^-1  (disjoint from (4))
         for (int idx = lane; idx < B * NP; idx += W::LANES) {
             const int p = idx / NP, i = idx - p * NP;
-            if (i < n && p < bs) {
+            if (i < nrow && p < bs) {
                 const int kp = k0 + p;
                 const bool in_blk = (i >= k0 && i < k0 + bs);
                 const double v = in_blk ? Pw[i - k0][p] : S.Wm[p][i];
@@ -323,26 +328,22 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
             K[tri_index(i, j)] = k;
         }
     }
-    for (int i = lane; i < n; i += W::LANES) S.r[i] = S.y[i] - mu;
+    for (int i = lane; i <= n; i += W::LANES) K[tri_index(n, i)] = (i < n) ? S.y[i] - mu : 0.0;   // augmented row
     W::sync();
     GP_T(4);
     double logdet;
     g[0] = g[1] = g[2] = g[3] = 0.0;
     if (!gp_sweep_inverse<W, NP, KP>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
     GP_T(5);      // (sweep total)
-    // alpha = K^-1 r = -(A r) with A symmetric packed ; r' K^-1 r = r . alpha
-    double ra = 0, sa = 0;
+    // alpha = the swept augmented row ; r' K^-1 r = -A(n, n)
+    double sa = 0;
     for (int i = lane; i < n; i += W::LANES) {
-        double s = 0;
-        for (int k = 0; k <= i; ++k) s += K[tri_index(i, k)] * S.r[k];
-        for (int k = i + 1; k < n; ++k) s += K[tri_index(k, i)] * S.r[k];
-        s = -s;
-        S.alpha[i] = s;
-        sa += s;
-        ra += S.r[i] * s;
+        const double v = K[tri_index(n, i)];
+        S.alpha[i] = v;
+        sa += v;
     }
-    ra = W::sum(ra);
     sa = W::sum(sa);
+    const double ra = -K[tri_index(n, n)];
     const double ll = -0.5 * (ra + logdet + n * GP_LOG_2PI);
     f = finite_d(ll) ? -ll : 1e25;
     W::sync();
@@ -461,7 +462,7 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, Ev&& gp_ev, int3
     }
     if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
 #ifdef LCFE_GP_PROF
-    if (st && lane == 0) for (int k = 0; k < 8; ++k) st[4 + k] = (int)(S.prof[k] >> 10);
+    if (st && lane == 0) for (int k = 0; k < 10; ++k) st[4 + k] = (int)(S.prof[k] >> 10);
 #endif
     if (!finite0 || !(finite_d(p[0]) && finite_d(p[1]) && finite_d(p[2]) && finite_d(p[3]))) { W::sync(); return; }
     // features read params[0..2] of george's vector [mean, log_constant, log_M_0_0, log_M_1_1] (:171-188)
