@@ -129,7 +129,7 @@ template <class W, int CAP>
 struct RunSet<W, SET_POWERLAW, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_POWERLAW, CAP>& ws, double* row, int32_t* st) {
         stage_object<W, CAP>(in, ws.obj);
-        powerlaw_object<W, CAP>(ws.obj, ws.fit, st);
+        powerlaw_object<typename FitPolicy<W>::type, W, CAP>(ws.obj, ws.fit, st);
         store_row<W>(ws.fit.out, row, POWERLAW_NCOL);
         W::sync();
     }

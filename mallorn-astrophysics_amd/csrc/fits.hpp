@@ -164,132 +164,170 @@ LCFE_FN void bazin_object(const ObjLds<CAP>& L, BazinLds<CAP>& S, int32_t* st) {
 
 // ---------------------------------------------------------------- post-peak decline models
 // train_v55_powerlaw.py:108-133.  pow(max(t - t0, 0.1), p): the kink makes the FD Jacobian part of
-// the semantics, so the models are evaluated exactly as written.
-template <int ID>
-struct DeclineModel;
+// the semantics, so the models are evaluated exactly as written.  The seven power laws differ only
+// in the exponent, which is DATA here: fits of different power laws then share one instruction
+// stream and can run side by side in different lane groups.
+struct PowerModel {            // A * max(t - t0, 0.1)^p     x = (A, t0)
+    static constexpr int NP = 2;
+    double p;
+    LCFE_FN double operator()(double t, const Vec<2>& x) const { return x[0] * pow(fmax(t - x[1], 0.1), p); }
+};
+struct ExpModel {              // A * exp(-max(t - t0, 0) / tau)   x = (A, tau, t0)
+    static constexpr int NP = 3;
+    LCFE_FN double operator()(double t, const Vec<3>& x) const { return x[0] * exp(-fmax(t - x[2], 0.0) / x[1]); }
+};
+struct LinModel {              // A - b * max(t - t0, 0)           x = (A, b, t0)
+    static constexpr int NP = 3;
+    LCFE_FN double operator()(double t, const Vec<3>& x) const { return x[0] - x[1] * fmax(t - x[2], 0.0); }
+};
 
-template <int ID>
-LCFE_FN constexpr double decline_exponent() {
-    return ID == 0 ? -5.0 / 3.0 : ID == 1 ? -1.0 : ID == 2 ? -1.5 : ID == 3 ? -2.0 : ID == 4 ? -2.5 : ID == 5 ? -3.0 : -0.5;
+LCFE_FN double decline_exponent(int id) {
+    // order of MODELS (train_v55_powerlaw.py:135-145): -5/3, -1, -1.5, -2, -2.5, -3, -0.5
+    const double e[7] = {-5.0 / 3.0, -1.0, -1.5, -2.0, -2.5, -3.0, -0.5};
+    return e[id];
 }
 
-template <int ID>
-struct DeclineModel {          // ID 0..6: A * max(t - t0, 0.1)^p     p = (A, t0)
-    static constexpr int NP = 2;
-    LCFE_FN double operator()(double t, const Vec<2>& p) const {
-        return p[0] * pow(fmax(t - p[1], 0.1), decline_exponent<ID>());
-    }
-};
-template <>
-struct DeclineModel<7> {       // exponential: A * exp(-max(t - t0, 0) / tau)   p = (A, tau, t0)
-    static constexpr int NP = 3;
-    LCFE_FN double operator()(double t, const Vec<3>& p) const { return p[0] * exp(-fmax(t - p[2], 0.0) / p[1]); }
-};
-template <>
-struct DeclineModel<8> {       // linear: A - b * max(t - t0, 0)               p = (A, b, t0)
-    static constexpr int NP = 3;
-    LCFE_FN double operator()(double t, const Vec<3>& p) const { return p[0] - p[1] * fmax(t - p[2], 0.0); }
-};
+// fit units in flight per band: two while the pool fits next to the staged object in 160 KiB of LDS
+template <int CAP> struct powerlaw_slots { static constexpr int SL = (CAP <= 512) ? 2 : 1; };
 
 template <int CAP>
 struct PowerlawLds {
-    union {                      // the n = 2 and n = 3 fits run one after the other in the same block
-        TrfLds<3, CAP> t3;
-        TrfLds<2, CAP> t2;
-    } trf;
-    double tp[CAP];              // post-peak times relative to the peak
+    static constexpr int SL = powerlaw_slots<CAP>::SL;
+    // pool of fit workspaces: every (band, slot) pair owns the rows [off, off + k_band + 3) of each column
+    double A[4][SL * CAP + 24];
+    double r[SL * CAP + 24], rn[SL * CAP + 24], w[SL * CAP + 24];
+    double tp[CAP];              // post-peak times relative to the peak (per band segment)
     double fp[CAP];              // post-peak fluxes
+    double peak[3], sstot[3];    // per band: peak flux, total sum of squares of the post-peak fluxes
+    int k[3], first[3];          // per band: number of post-peak rows (or -1: no fits), first post-peak row
     double out[POWERLAW_NCOL];
 };
 
 template <int N, int CAP>
-LCFE_FN TrfLds<N, CAP>& trf_block(PowerlawLds<CAP>& S) {
-    if constexpr (N == 2) return S.trf.t2;
-    else return S.trf.t3;
+LCFE_FN TrfView<N> powerlaw_view(PowerlawLds<CAP>& S, int off) {
+    TrfView<N> v;
+#pragma unroll
+    for (int c = 0; c <= N; ++c) v.A[c] = S.A[c] + off;
+    v.r = S.r + off;
+    v.rn = S.rn + off;
+    v.w = S.w + off;
+    return v;
 }
 
-template <class W, int ID, int CAP>
-LCFE_FN TrfResult decline_fit(int k, double peak_flux, double mean_post, double ss_tot, PowerlawLds<CAP>& S,
-                              double* out) {
-    using M = DeclineModel<ID>;
+// one bounded fit of `model` to the k post-peak rows (tp, fp) -> R^2   (train_v55_powerlaw.py:170-192)
+template <class W, class M>
+LCFE_FN TrfResult decline_fit(const M& model, const double* tp, const double* fp, int k, double peak_flux,
+                              double ss_tot, int kind, TrfView<M::NP>& T, double* out) {
     constexpr int N = M::NP;
     const int lane = W::lane();
     Vec<N> x, lb, ub;
     if (N == 2) {                                                 // :172-175
         x[0] = peak_flux; x[1] = 0;
         lb[0] = 0; lb[1] = -10; ub[0] = 1e6; ub[1] = 10;
-    } else if (ID == 7) {                                         // :177-180
+    } else if (kind == 7) {                                       // :177-180 exponential
         x[0] = peak_flux; x[1] = 30; x[N - 1] = 0;
         lb[0] = 0; lb[1] = 1; lb[N - 1] = -10; ub[0] = 1e6; ub[1] = 500; ub[N - 1] = 10;
-    } else {                                                      // :181-184
+    } else {                                                      // :181-184 linear
         x[0] = peak_flux; x[1] = 1; x[N - 1] = 0;
         lb[0] = 0; lb[1] = 0; lb[N - 1] = -10; ub[0] = 1e6; ub[1] = 100; ub[N - 1] = 10;
     }
-    TrfLds<N, CAP>& T = trf_block<N>(S);
     for (int i = lane; i < k; i += W::LANES) T.w[i] = 1.0;        // unweighted: r = model - y
     W::sync();
-    M model;
-    TrfResult res = trf_fit<W, M, TrfLds<N, CAP>>(model, S.tp, S.fp, k, x, lb, ub, 1000, T);
+    TrfResult res = trf_fit<W, M, TrfView<N>>(model, tp, fp, k, x, lb, ub, 1000, T);
     if (res.status <= 0) {                                        // :191-192
         if (lane == 0) *out = qnan();
         return res;
     }
     double ss = 0;
-    for (int i = lane; i < k; i += W::LANES) { const double r = S.fp[i] - model(S.tp[i], x); ss += r * r; }   // :186-187
+    for (int i = lane; i < k; i += W::LANES) { const double r = fp[i] - model(tp[i], x); ss += r * r; }   // :186-187
     ss = W::sum(ss);
     if (lane == 0) *out = (ss_tot > 0) ? 1.0 - ss / ss_tot : 0.0;       // :189
     return res;
 }
 
-// train_v55_powerlaw.py:147-194 for one band (time-sorted rows) -> 9 R^2 values
-template <class W, int CAP>
-LCFE_FN void decline_band(const double* t, const double* f, int m, PowerlawLds<CAP>& S, double* out9,
-                          int32_t* st) {
-    const int lane = W::lane();
-    auto fail_all = [&](int code) {
-        if (lane == 0) for (int j = 0; j < 9; ++j) out9[j] = qnan();
-        if (st && lane == 0) for (int j = 0; j < 9; ++j) { st[2 * j] = code; st[2 * j + 1] = 0; }
-    };
-    if (m < 5) { fail_all(TRF_FAIL_TOO_FEW); return; }            // :150-151
-    const int pk = wave_argmax_first<W>(f, m);                    // :157
-    const double peak_time = t[pk], peak_flux = f[pk];
-    // post-peak rows: t > peak_time (:161); rows are time-sorted, so they form a suffix -- but
-    // equal time stamps after the peak are excluded by the strict comparison, so count explicitly
-    int first = m;
-    for (int i = lane; i < m; i += W::LANES) if (t[i] > peak_time) first = (i < first) ? i : first;
-    first = W::min(first);
-    const int k = m - first;
-    if (k < 3) { fail_all(TRF_FAIL_TOO_FEW); return; }            // :162-163
-    double sum = 0;
-    for (int i = lane; i < k; i += W::LANES) {
-        S.tp[i] = t[first + i] - peak_time;                       // :165
-        S.fp[i] = f[first + i];
-        sum += f[first + i];
-    }
-    sum = W::sum(sum);
-    const double mean_post = sum / k;
-    W::sync();
-    double ss_tot = 0;
-    for (int i = lane; i < k; i += W::LANES) { const double d = S.fp[i] - mean_post; ss_tot += d * d; }    // :188
-    ss_tot = W::sum(ss_tot);
-    TrfResult r;
-#define LCFE_DECLINE(ID)                                                                  \
-    r = decline_fit<W, ID, CAP>(k, peak_flux, mean_post, ss_tot, S, out9 + ID);           \
-    if (st && lane == 0) { st[2 * ID] = r.status; st[2 * ID + 1] = r.nfev; }             \
-    W::sync();
-    LCFE_DECLINE(0) LCFE_DECLINE(1) LCFE_DECLINE(2) LCFE_DECLINE(3) LCFE_DECLINE(4)
-    LCFE_DECLINE(5) LCFE_DECLINE(6) LCFE_DECLINE(7) LCFE_DECLINE(8)
-#undef LCFE_DECLINE
-}
-
-template <class W, int CAP>
+// W: policy of ONE FIT (an 8-lane group on the device: up to six fits side by side -- three bands x
+// two slots); WW: policy of the whole wave.
+template <class W, class WW, int CAP>
 LCFE_FN void powerlaw_object(const ObjLds<CAP>& L, PowerlawLds<CAP>& S, int32_t* st) {
-    for (int j = 0; j < 3; ++j) {                                 // :198 bands g, r, i
+    const int g = W::group_id();
+    // ---- per band (train_v55_powerlaw.py:147-166): peak, post-peak rows, their sum of squares
+    for (int j = g; j < 3; j += W::NGROUPS) {
         const int kb = j + 1;
         const int s = L.boff[kb], m = L.boff[kb + 1] - s;
-        decline_band<W, CAP>(L.bt + s, L.bf + s, m, S, S.out + 9 * j, st ? st + 18 * j : nullptr);
+        const double* t = L.bt + s;
+        const double* f = L.bf + s;
+        int k = -1, first = 0;
+        double peak_flux = 0, ss_tot = 0;
+        if (m >= 5) {                                             // :150-151
+            const int pk = wave_argmax_first<W>(f, m);            // :157
+            const double peak_time = t[pk];
+            peak_flux = f[pk];
+            first = m;
+            for (int i = W::lane(); i < m; i += W::LANES) if (t[i] > peak_time) first = (i < first) ? i : first;   // :161
+            first = W::min(first);
+            k = m - first;
+            if (k < 3) k = -1;                                    // :162-163
+            else {
+                double sum = 0;
+                for (int i = W::lane(); i < k; i += W::LANES) {
+                    S.tp[s + i] = t[first + i] - peak_time;       // :165
+                    S.fp[s + i] = f[first + i];
+                    sum += f[first + i];
+                }
+                const double mean_post = W::sum(sum) / k;
+                W::sync();
+                double q = 0;
+                for (int i = W::lane(); i < k; i += W::LANES) { const double d = S.fp[s + i] - mean_post; q += d * d; }   // :188
+                ss_tot = W::sum(q);
+            }
+        }
+        if (W::lane() == 0) { S.k[j] = k; S.first[j] = first; S.peak[j] = peak_flux; S.sstot[j] = ss_tot; }
         W::sync();
     }
+    WW::sync();
+    // ---- 27 fits: unit u = band j (0..2) x slot; with two slots, slot 0 takes the power laws 0,2,4,6
+    // and the exponential, slot 1 the power laws 1,3,5 and the linear model
+    constexpr int SL = powerlaw_slots<CAP>::SL;
+    constexpr int NUNIT = 3 * SL;
+    constexpr int NU = (W::NGROUPS >= NUNIT) ? NUNIT : W::NGROUPS;     // units in flight
+    for (int u = g; u < NUNIT; u += NU) {
+        if (g >= NU) break;
+        const int j = u % 3, slot = u / 3;
+        const int kb = j + 1;
+        const int s = L.boff[kb];
+        const int k = S.k[j];
+        double* out9 = S.out + 9 * j;
+        int32_t* stj = st ? st + 18 * j : nullptr;
+        if (k < 0) {
+            if (W::lane() == 0) {
+                for (int id = slot; id < 9; id += SL) { out9[id] = qnan(); if (stj) { stj[2 * id] = TRF_FAIL_TOO_FEW; stj[2 * id + 1] = 0; } }
+            }
+            continue;
+        }
+        // workspace rows of this unit: both slots of a band fit inside 2*(band length) + 6 rows
+        const int off = SL * (s - L.boff[1]) + 3 * SL * j + slot * (k + 3);
+        const double* tp = S.tp + s;
+        const double* fp = S.fp + s;
+        for (int id = slot; id < 7; id += SL) {
+            TrfView<2> T = powerlaw_view<2, CAP>(S, off);
+            PowerModel model{decline_exponent(id)};
+            TrfResult r = decline_fit<W, PowerModel>(model, tp, fp, k, S.peak[j], S.sstot[j], id, T, out9 + id);
+            if (stj && W::lane() == 0) { stj[2 * id] = r.status; stj[2 * id + 1] = r.nfev; }
+            W::sync();
+        }
+        TrfView<3> T3 = powerlaw_view<3, CAP>(S, off);
+        if (slot == 0) {
+            TrfResult r = decline_fit<W, ExpModel>(ExpModel(), tp, fp, k, S.peak[j], S.sstot[j], 7, T3, out9 + 7);
+            if (stj && W::lane() == 0) { stj[14] = r.status; stj[15] = r.nfev; }
+            W::sync();
+        }
+        if (slot == SL - 1) {
+            TrfResult r = decline_fit<W, LinModel>(LinModel(), tp, fp, k, S.peak[j], S.sstot[j], 8, T3, out9 + 8);
+            if (stj && W::lane() == 0) { stj[16] = r.status; stj[17] = r.nfev; }
+            W::sync();
+        }
+    }
+    WW::sync();
 }
 
 }  // namespace lcfe
