@@ -152,6 +152,73 @@ LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs
     }
 }
 
+// Pw <- -(identity-padded pivot block)^-1 by B single-index sweeps; returns true on a non-positive
+// pivot and adds log(pivots) to ld.  On the GPU the 8 x 8 block lives in the registers of one
+// wavefront (lane e holds element (e/8, e%8)) and the pivot row / column are fetched with lane
+// shuffles -- no LDS round trip per pivot; the host simulation goes through the Pw array.
+template <class W, int NP>
+LCFE_FN bool gp_pivot_inverse(GpLds<NP, W::NWAVES>& S, double (*Pw)[gp_block<NP>::B], int k0, int bs, double& ld) {
+    constexpr int B = gp_block<NP>::B;
+    bool bad = false;
+    double prod = 1.0;
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64 && B == 8) {
+        const int e = W::wlane();
+        const int a = e >> 3, b = e & 7;
+        double p = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            const double d = __shfl(p, q * 9, 64);                 // pivot (q, q): uniform
+            const double paq = __shfl(p, (e & ~7) | q, 64);        // (a, q)
+            const double pqb = __shfl(p, (q << 3) | b, 64);        // (q, b)
+            if (!(d > 0.0)) bad = true;
+            prod *= d;
+            const double inv = 1.0 / d;
+            double v = p - paq * pqb * inv;
+            if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
+            if (a == q && b == q) v = -inv;
+            p = v;
+        }
+        ld += log(prod);
+        Pw[a][b] = p;
+        W::wave_sync();
+        return bad;
+    }
+#endif
+    for (int e = W::wlane(); e < B * B; e += W::WAVE) {
+        const int a = e / B, b = e % B;
+        Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+    }
+    W::wave_sync();
+    for (int q = 0; q < B; ++q) {
+        const double d = Pw[q][q];
+        if (!(d > 0.0)) bad = true;
+        prod *= d;
+        if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }          // one log per 8 pivots (no overflow)
+        const double inv = 1.0 / d;
+        constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
+        double nv[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int e = W::wlane() + c * W::WAVE;
+            const int a = e / B, b = e % B;
+            const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
+            double v = pab - paq * pqb * inv;
+            if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
+            if (a == q && b == q) v = -inv;
+            nv[c] = v;
+        }
+        W::wave_sync();
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int e = W::wlane() + c * W::WAVE;
+            Pw[e / B][e % B] = nv[c];
+        }
+        W::wave_sync();
+    }
+    return bad;
+}
+
 // Wm = V^T * (-Pw): 16 rows of the matrix per MFMA pair on the GPU (B operand = the 8 x 8 block
 // padded to 16 columns), one row per lane otherwise.
 template <class W, int NP>
@@ -230,38 +297,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
         //     wave-level hand-offs: every wavefront on its own copy, or wave 0 on a shared one
         bool bad = false;
         if (PER_WAVE || W::wave_id() == 0) {
-            for (int e = W::wlane(); e < B * B; e += W::WAVE) {
-                const int a = e / B, b = e % B;
-                Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
-            }
-            W::wave_sync();
-            double prod = 1.0;
-            for (int q = 0; q < B; ++q) {
-                const double d = Pw[q][q];
-                if (!(d > 0.0)) bad = true;                     // identical in every wavefront -> uniform
-                prod *= d;
-                if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }      // one log per 8 pivots (no overflow)
-                const double inv = 1.0 / d;
-                constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
-                double nv[NV];
-#pragma unroll
-                for (int c = 0; c < NV; ++c) {
-                    const int e = W::wlane() + c * W::WAVE;
-                    const int a = e / B, b = e % B;
-                    const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
-                    double v = pab - paq * pqb * inv;
-                    if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
-                    if (a == q && b == q) v = -inv;
-                    nv[c] = v;
-                }
-                W::wave_sync();
-#pragma unroll
-                for (int c = 0; c < NV; ++c) {
-                    const int e = W::wlane() + c * W::WAVE;
-                    Pw[e / B][e % B] = nv[c];
-                }
-                W::wave_sync();
-            }
+            bad = gp_pivot_inverse<W, NP>(S, Pw, k0, bs, ld);
             if (!PER_WAVE && bad && W::wlane() == 0) S.pivot_bad = 1;
         }
         if (!PER_WAVE) {

@@ -15,7 +15,6 @@
 
 #include "../../include/lcfe.h"
 #include "feature_sets.hpp"
-#include "gp_reg.hpp"
 
 using namespace lcfe;
 
@@ -140,50 +139,6 @@ __global__ __launch_bounds__(GLOBAL_K ? 1024 : 256) void gp_kernel(BatchView B, 
     }
 }
 
-// Register-resident tiers: the matrix of a light curve with n + 1 <= TS*T rows lives in the
-// registers of a TS x TS thread grid (gp_reg.hpp).
-template <int TS, int T>
-__global__ __launch_bounds__(TS * TS) void gp_reg_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
-                                                         int col0, int32_t* status, int st_ld, int st0) {
-    using W = BlockDev<TS * TS>;
-    constexpr int NP = TS * T;
-    __shared__ GpLds<NP, W::NWAVES> S;
-    for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
-        const int64_t s = B.offsets[i];
-        const int64_t n64 = B.offsets[i + 1] - s;
-        if (n64 <= lo) continue;
-        double* row = out + i * (int64_t)ld + col0;
-        int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
-        if (n64 > hi) {
-            if (last_tier) {
-                fill_row_nan<W>(row, GP_NCOL);
-                if (st && threadIdx.x < 4) st[threadIdx.x] = -100;
-            }
-            continue;
-        }
-        ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
-        gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
-            gp_eval_reg<W, NP, TS, T>(x, n, S, f, g, need); }, st);
-        store_row<W>(S.out, row, GP_NCOL);
-        __syncthreads();
-    }
-}
-
-template <int TS, int T>
-int launch_gp_reg_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
-                       int st_ld, int st0, hipStream_t stream, int dev) {
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_reg_kernel<TS, T>, TS * TS, 0));
-    if (per_cu < 1) per_cu = 1;
-    int64_t grid = (int64_t)num_cus(dev) * per_cu;
-    if (grid > B.n_obj) grid = B.n_obj;
-    if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp_reg_kernel<TS, T>), dim3((unsigned)grid), dim3(TS * TS), 0, stream, B, lo, hi, last, out, ld,
-                       col0, status, st_ld, st0);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 template <int NP, bool GLOBAL_K>
 int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
                    int st_ld, int st0, hipStream_t stream, int dev, double* kscratch) {
@@ -203,13 +158,11 @@ int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, in
 
 int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
               int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch) {
-    // window (lo, hi] on the ROW count of the object (>= its valid points; one spare slot is kept
-    // for the augmented row of the register variant, so the caps are NP - 1).
-    // Measured on MI355X (20k-object batch): the register-resident variant (gp_reg_kernel) is SLOWER
-    // than the LDS-resident sweep -- hipcc spends 412-512 registers per lane on the fully unrolled
-    // tile passes (1 workgroup per CU) and spills at 1024 threads -- so it is compiled and parity-
-    // tested but not scheduled (tiers: reg<16,5> 52 ms / reg<16,8> 164 / reg<16,12> 558 / reg<32,8>
-    // 1700 vs LDS<64> 25 / <120> 179 / <176> 386).
+    // window (lo, hi] on the ROW count of the object (>= its valid points); one row of the tile
+    // storage is the augmented residual row, so the caps are NP - 1.
+    // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
+    // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
+    // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
     const int caps[4] = {63, 111, 159, kGpGlobalNP - 1};
     int last = 0;
     while (last < 3 && caps[last] < max_len) ++last;

@@ -8,7 +8,6 @@
 #include <vector>
 
 #include "../../mallorn-astrophysics_amd/csrc/feature_sets.hpp"
-#include "../../mallorn-astrophysics_amd/csrc/gp_reg.hpp"
 
 using namespace lcfe;
 
@@ -56,10 +55,10 @@ static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const
         ObjIn in{t + s, flux + s, err + s, band + s, n, qnan()};
         int32_t* st = status ? status + set_nstatus(SET_GP2D) * i : nullptr;
         const double* o;
-        // short light curves: register-tiled evaluation (one-lane grid: TS = 1); longer: tiled-matrix sweep
-        if (n + 1 <= 120) {
+        // like the device: the small working set for short light curves, the large one otherwise
+        if (n + 1 <= NS) {
             gp_object<W, NS>(in, *ws, [&](const double* x, int nn, double& f, double* g, bool need) {
-                gp_eval_reg<W, NS, 1, NS>(x, nn, *ws, f, g, need); }, st);
+                gp_eval<W, NS, double*>(x, nn, *ws, K.data(), f, g, need); }, st);
             o = ws->out;
         } else {
             gp_object<W, NL>(in, *wl, [&](const double* x, int nn, double& f, double* g, bool need) {

@@ -230,3 +230,32 @@ def test_entry_point_scripts_write_the_caches(tmp_path):
     r = subprocess.run([_sys.executable, os.path.join(ROOT, "scripts", "precompute_features.py")], env=env,
                        capture_output=True, text=True)
     assert r.stdout.count("already cached") == 6
+
+
+def test_full_size_properties():
+    """BASELINE config sizes (10,178 objects): properties that do not need the oracle --
+    run-to-run bit identity, independence of the rows from batch order and batch composition."""
+    n = 10178
+    lc = synth.make_lightcurves(n, seed=10178)
+    sets = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d"]
+    a = extract_csr(sets, lc, z=lc["z"])
+    b = extract_csr(sets, lc, z=lc["z"])
+    assert a.shape == (n, 434)
+    key = lambda m: np.nan_to_num(m, nan=-7.25e300)
+    assert np.array_equal(key(a), key(b)), "two runs on the same input differ"
+    # reversed object order -> the same rows, reversed
+    import synth_subset
+    rev = synth_subset.take(lc, list(range(n - 1, -1, -1)))
+    c = extract_csr(sets, rev, z=rev["z"])
+    assert np.array_equal(key(c[::-1]), key(a)), "rows depend on the position of the object in the batch"
+    # a subset computed alone equals its rows in the full batch
+    rows = list(range(0, n, 37))
+    sub = synth_subset.take(lc, rows)
+    d = extract_csr(sets, sub, z=sub["z"])
+    assert np.array_equal(key(d), key(a[rows])), "rows depend on the other objects of the batch"
+    # integer columns are integers, counts add up
+    cols = COLUMNS["stat"]
+    nobs = a[:, [cols.index(f"{p}_n_obs") for p in "ugrizy"]]
+    assert np.array_equal(nobs, np.round(nobs))
+    assert np.array_equal(nobs.sum(1), a[:, cols.index("all_n_obs")])
+    assert np.array_equal(a[:, cols.index("all_n_obs")], np.diff(lc["offsets"]).astype(float))
