@@ -35,10 +35,9 @@ template <class P> struct gp_is_lds_ptr { static constexpr bool value = false; }
 template <> struct gp_is_lds_ptr<lds_double*> { static constexpr bool value = true; };
 #endif
 
-// pivot-block width of the sweep.  16 was measured twice for the global-scratch tier (1284 ms vs
-// 1093 ms for the 20k-object batch): no gain -- that tier is bound by per-element latency and
-// instruction issue, not by the number of passes over the L2/MALL-resident matrix.
-template <int NP> struct gp_block { static constexpr int B = 8; };
+// pivot-block width of the sweep: 8 for the LDS tiers and the 768-point fallback, 16 for the
+// 512-point global-scratch tier (half as many block steps, each with four MFMAs per tile)
+template <int NP> struct gp_block { static constexpr int B = (NP == 512) ? 16 : 8; };
 
 // Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
 // doubles) lives in LDS for the small tiers and in a per-workgroup slab of global scratch otherwise.
@@ -82,7 +81,9 @@ typedef double gp_v4f64 __attribute__((ext_vector_type(4)));
 // register v = (row l/16 + 4v, col l%16)); the host simulation uses plain loops.
 template <class W, int NP, class KP>
 LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs) {   // n = rows incl. the augmented one
-    static_assert(gp_block<NP>::B == 8, "two 16x16x4 MFMAs cover an 8-wide pivot block");
+    constexpr int B = gp_block<NP>::B;
+    constexpr int KC = B / 4;                   // 16x16x4 MFMAs per tile
+    (void)KC;
     const int nt = (n + 15) >> 4;
 #if defined(__HIPCC__)
     if constexpr (W::WAVE == 64) {
@@ -94,7 +95,7 @@ LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs
             int ti[UNR], tj[UNR];
             bool on[UNR];
             gp_v4f64 c[UNR];
-            double a0[UNR], a1[UNR], b0[UNR], b1[UNR];
+            double av[UNR][KC], bv[UNR][KC];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int t = t0 + u;
@@ -115,14 +116,13 @@ LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ri = (ti[u] << 4) + lc, cj = (tj[u] << 4) + lc;   // operand row / column of this lane
-                a0[u] = -S.Wm[lr][ri]; a1[u] = -S.Wm[4 + lr][ri];
-                b0[u] = S.V[lr][cj]; b1[u] = S.V[4 + lr][cj];
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) { av[u][kc] = -S.Wm[4 * kc + lr][ri]; bv[u][kc] = S.V[4 * kc + lr][cj]; }
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c[u], 0, 0, 0);
-                c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c[u], 0, 0, 0);
-            }
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][kc], bv[u][kc], c[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (!on[u]) continue;
@@ -228,15 +228,18 @@ LCFE_FN void gp_row_weights(GpLds<NP, W::NWAVES>& S, const double (*Pw)[gp_block
     if constexpr (W::WAVE == 64) {
         const int l = W::wlane();
         const int lr = l >> 4, lc = l & 15;
-        // B operand: (k = lr [+4], col = lc): -Pw[k][col] for col < 8, zero padding beyond
-        const double b0 = (lc < B) ? -Pw[lr][lc] : 0.0, b1 = (lc < B) ? -Pw[4 + lr][lc] : 0.0;
+        // B operand: (k = 4 kc + lr, col = lc): -Pw[k][col] for col < B, zero padding beyond
+        constexpr int KC = B / 4;
+        double bq[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) bq[kc] = (lc < B) ? -Pw[4 * kc + lr][lc] : 0.0;
         const int nt = (n + 15) >> 4;
         for (int t = W::wave_id(); t < nt; t += W::NWAVES) {
             const int ri = (t << 4) + lc;
-            const double a0 = S.V[lr][ri], a1 = S.V[4 + lr][ri];          // A operand: (row = lc, k = lr [+4])
             gp_v4f64 c = {0, 0, 0, 0};
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)                                   // A operand: (row = lc, k = 4 kc + lr)
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(S.V[4 * kc + lr][ri], bq[kc], c, 0, 0, 0);
             // D lane (row = lr + 4v, col = lc): Wm[col][row]
             if (lc < B) {
 #pragma unroll

@@ -101,9 +101,10 @@ int num_cus(int dev);
 
 // ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 176) or,
 // for longer light curves, in a per-workgroup slab of global scratch.
-constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one 1024-thread workgroup per CU
+constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks
+constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (fallback for 512..767 rows)
 constexpr int kGpGlobalGrid = 256;
-constexpr size_t kGpMidBytes = 0;
+constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
 template <int NP, bool GLOBAL_K>
@@ -176,7 +177,8 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
             case 0: rc = launch_gp_tier<64, false>(B, lo, caps[0], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 1: rc = launch_gp_tier<112, false>(B, lo, caps[1], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
             case 2: rc = launch_gp_tier<160, false>(B, lo, caps[2], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 3: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, caps[3], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
+            case 3: rc = launch_gp_tier<kGpMidNP, true>(B, lo, caps[3], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
+            case 4: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, caps[4], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch + kGpMidBytes / 8); break;
         }
         if (rc) return rc;
         ++*n_launch;

@@ -45,7 +45,7 @@ static void run_all(int64_t n_obj, const int64_t* offsets, const double* t, cons
 static void run_gp(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux, const double* err,
                    const uint8_t* band, double* out, int32_t* status) {
     using W = WaveHost;
-    constexpr int NS = 176, NL = 768;
+    constexpr int NS = 176, NL = 512;      // NL = 512 exercises the 16-wide sweep
     auto ws = std::make_unique<GpLds<NS, 1>>();
     auto wl = std::make_unique<GpLds<NL, 1>>();
     std::vector<double> K((size_t)gp_store_doubles(NL));
