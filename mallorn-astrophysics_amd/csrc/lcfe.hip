@@ -107,10 +107,12 @@ constexpr int kGpGlobalGrid = 256;
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
+template <int NP> struct gp_threads { static constexpr int T = (NP >= 512) ? 1024 : ((NP >= 112) ? 512 : 256); };
+
 template <int NP, bool GLOBAL_K>
-__global__ __launch_bounds__(GLOBAL_K ? 1024 : 256) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
+__global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch) {
-    using W = BlockDev<(GLOBAL_K ? 1024 : 256)>;
+    using W = BlockDev<gp_threads<NP>::T>;
     __shared__ GpLds<NP, W::NWAVES> S;
     __shared__ double Klds[GLOBAL_K ? 1 : gp_store_doubles(NP)];
     double* Kg = kscratch + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
@@ -144,7 +146,7 @@ template <int NP, bool GLOBAL_K>
 int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
                    int st_ld, int st0, hipStream_t stream, int dev, double* kscratch) {
     int per_cu = 0;
-    constexpr int threads = GLOBAL_K ? 1024 : 256;
+    constexpr int threads = gp_threads<NP>::T;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, threads, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
