@@ -112,7 +112,9 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    if world > 1:
+    # LCFE_BENCH_FORCE_DIST=1: one-rank rehearsal of the RCCL path on a single-GPU box
+    use_dist = world > 1 or os.environ.get("LCFE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     lib = _lib.load()
     impl = lib.lcfe_implemented_mask()
@@ -124,16 +126,16 @@ def main():
     lc = synth.make_lightcurves(a.objects, seed=a.seed + rank)
     batch = DeviceBatch(lc, z=lc["z"], device=local)
     out = torch.empty((a.objects, ncol), dtype=torch.float64, device=batch.device)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step(prof=False):
         r = batch.run(mask, out=out, prof=prof)
-        if world > 1:
+        if use_dist:
             dist.gather(out, gathered, dst=0)
         return r[2] if prof else None
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,12 +157,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=batch.device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     n_pts = int(lc["offsets"][-1])
@@ -195,7 +196,7 @@ def main():
         note("timing the CPU oracle on the host cores")
         res["cpu_baseline"] = cpu_baseline(sets, lc)
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

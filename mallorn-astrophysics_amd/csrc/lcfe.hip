@@ -99,8 +99,9 @@ __global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_t
 
 int num_cus(int dev);
 
-// ---- 2-D GP: one light curve per 256-thread workgroup; packed Gram matrix in LDS (NP <= 176) or,
-// for longer light curves, in a per-workgroup slab of global scratch.
+// ---- 2-D GP: one light curve per workgroup (256/512/1024 threads by tier); Gram matrix as 16x16
+// lower-triangle tiles in LDS (NP <= 160) or, for longer light curves, in a per-workgroup slab of
+// global scratch.
 constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks
 constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (fallback for 512..767 rows)
 constexpr int kGpGlobalGrid = 256;
@@ -166,9 +167,9 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
-    const int caps[4] = {63, 111, 159, kGpGlobalNP - 1};
+    const int caps[5] = {63, 111, 159, kGpMidNP - 1, kGpGlobalNP - 1};
     int last = 0;
-    while (last < 3 && caps[last] < max_len) ++last;
+    while (last < 4 && caps[last] < max_len) ++last;
     if (last >= 3 && kscratch_bytes < kGpMidBytes + kGpGlobalBytes)
         return fail_msg("lcfe_extract_device: workspace too small for the GP global tier");
     int lo = -1;

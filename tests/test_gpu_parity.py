@@ -190,15 +190,18 @@ def test_gp2d_vs_oracle(golden_inputs):
 def test_gp2d_long_objects_use_global_tier():
     rng = np.random.default_rng(3)
     objs = []
-    for n in (60, 130, 191, 400):
+    for n in (60, 130, 191, 400, 600, 800):      # 800 > the 767-row limit: NaN row, status -100
         t = np.sort(59000 + rng.uniform(0, 300, n))
         b = rng.choice(6, n)
         f = 30 * np.exp(-0.5 * ((t - 59100) / 30) ** 2) * (1 + 0.1 * b) + rng.normal(0, 1, n)
         objs.append((t, f, np.full(n, 1.0), b))
     lc = synth.from_objects(objs)
-    got = extract_csr("gp2d", lc)
-    ref = oracle.extract("gp2d", lc)
-    bad = parity.compare(got, ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
+    got, st = extract_csr("gp2d", lc, return_status=True)
+    assert np.isnan(got[5]).all() and st[5, 0] == -100
+    assert not np.isnan(got[:5, :3]).any()
+    keep = synth.from_objects(objs[:5])
+    ref = oracle.extract("gp2d", keep)
+    bad = parity.compare(got[:5], ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
     assert len(bad) <= 2, "\n".join(bad)
 
 
