@@ -145,6 +145,105 @@ LCFE_FN void wave_select_ranks(const double* x, int m, unsigned long long* keys,
     W::sync();
 }
 
+// ---- ascending sorting network over the LANES x KPL values a lane group holds in registers
+// (element index = lane * KPL + r).  Bitonic merges in the direction-free form: the first step of a
+// size-K merge compares i with its mirror i ^ (K-1), the following half-cleaners compare i with
+// i ^ J for J = K/4 ... 1; the lower index always keeps the minimum.  Partners closer than KPL are
+// other registers of the same lane, the rest are fetched from lane ^ (J / KPL) (DPP / swizzle).
+// The values must not contain NaN (callers branch on that before; pad with +inf).
+template <class W, int KPL, int K>
+LCFE_FN void sort_flip_step(double (&v)[KPL]) {
+    if constexpr (K <= KPL) {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int q = r ^ (K - 1);
+            if (r < q) { const double a = v[r], b = v[q]; v[r] = dmin(a, b); v[q] = dmax(a, b); }
+        }
+    } else {
+        constexpr int ML = K / KPL - 1;
+        const bool keep_min = (W::lane() & ((ML + 1) >> 1)) == 0;
+        double p[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) p[r] = W::template xfetch<ML>(v[KPL - 1 - r]);
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) { const double lo = dmin(v[r], p[r]), hi = dmax(v[r], p[r]); v[r] = keep_min ? lo : hi; }
+    }
+}
+template <class W, int KPL, int J>
+LCFE_FN void sort_half_steps(double (&v)[KPL]) {
+    if constexpr (J >= 1) {
+        if constexpr (J < KPL) {
+#pragma unroll
+            for (int r = 0; r < KPL; ++r)
+                if ((r & J) == 0) { const double a = v[r], b = v[r | J]; v[r] = dmin(a, b); v[r | J] = dmax(a, b); }
+        } else {
+            constexpr int ML = J / KPL;
+            const bool keep_min = (W::lane() & ML) == 0;
+            double p[KPL];
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) p[r] = W::template xfetch<ML>(v[r]);
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) { const double lo = dmin(v[r], p[r]), hi = dmax(v[r], p[r]); v[r] = keep_min ? lo : hi; }
+        }
+        sort_half_steps<W, KPL, J / 2>(v);
+    }
+}
+template <class W, int KPL, int K>
+LCFE_FN void sort_merges(double (&v)[KPL]) {
+    if constexpr (K <= W::LANES * KPL) {
+        sort_flip_step<W, KPL, K>(v);
+        sort_half_steps<W, KPL, K / 4>(v);
+        sort_merges<W, KPL, K * 2>(v);
+    }
+}
+
+// sorted[0..m) = x[0..m) in ascending order (x NaN-free, m <= LANES * KPL; `sorted` may not alias x).
+// With one lane (host build) this is a plain insertion sort.
+template <class W, int KPL>
+LCFE_FN void group_sort_values(const double* x, int m, double* sorted) {
+    if constexpr (W::LANES == 1) {
+        for (int i = 0; i < m; ++i) {
+            const double v = x[i];
+            int j = i;
+            while (j > 0 && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; --j; }
+            sorted[j] = v;
+        }
+    } else {
+        const int base = W::lane() * KPL;
+        double v[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) v[r] = (base + r < m) ? x[base + r] : __builtin_inf();
+        sort_merges<W, KPL, 2>(v);
+#pragma unroll
+        for (int r = 0; r < KPL; ++r)
+            if (base + r < m) sorted[base + r] = v[r];
+    }
+    W::sync();
+}
+
+// median(|s_i - med|) of an ascending array s[0..m) whose median is `med` (finite): the deviations of
+// the upper half [h, m) ascend, those of the lower half descend, so the two middle ranks of their
+// merge are found by a bisection on "how many come from the upper half" -- every deviation is the
+// same floating-point subtraction numpy performs, so the result is exact.  Uniform over the group.
+LCFE_FN double mad_of_sorted(const double* s, int m, double med) {
+    const int h = m / 2, a = m - h, b = h;
+    const int r = (m - 1) / 2;                 // lower middle rank; the upper one is m / 2
+    int lo = (r + 1 - b > 0) ? r + 1 - b : 0, hi = (a < r + 1) ? a : r + 1;
+    while (lo < hi) {
+        const int i = (lo + hi) >> 1, j = r + 1 - i;
+        if (s[h + i] - med < med - s[h - j]) lo = i + 1; else hi = i;
+    }
+    const int i = lo, j = r + 1 - i;
+    double v_lo = -__builtin_inf();
+    if (i > 0) v_lo = s[h + i - 1] - med;
+    if (j > 0) { const double d = med - s[h - j]; v_lo = (d > v_lo) ? d : v_lo; }
+    if (r == m / 2) return v_lo;
+    double v_hi = __builtin_inf();
+    if (i < a) v_hi = s[h + i] - med;
+    if (j < b) { const double d = med - s[h - 1 - j]; v_hi = (d < v_hi) ? d : v_hi; }
+    return (v_lo + v_hi) / 2.0;
+}
+
 // numpy.argmax semantics on a (wave-shared) array: index of the FIRST maximum; a NaN counts as
 // the maximum (numpy propagates the first NaN).  Returns -1 for m == 0.  Uniform result.
 template <class W>

@@ -26,7 +26,9 @@ LCFE_FN double np_lerp(double a, double b, double t) {
 // (`time_sorted` says whether that holds; if not, neighbours are found by a successor scan);
 // ge: the group's errors in the same order.  `sel` is 8 doubles of wave-shared scratch,
 // `dev` m doubles of wave-shared scratch.  out17 is wave-shared; lane 0 writes it.
-template <class W>
+// KPL > 0: the group sorts its fluxes once (LANES x KPL register network, m <= LANES * KPL) and
+// reads the order statistics off the sorted copy; KPL == 0: rank counting (any m).
+template <class W, int KPL>
 LCFE_FN void group_statistics(const double* gt, const double* gf, const double* ge, int m,
                               bool time_sorted, double* sel, double* dev, unsigned long long* keys, double* out17) {
     const int lane = W::lane();
@@ -100,29 +102,44 @@ LCFE_FN void group_statistics(const double* gt, const double* gf, const double* 
     const double v25 = 0.25 * (m - 1), v75 = 0.75 * (m - 1);
     const int r25 = (int)floor(v25), r75 = (int)floor(v75);
     const int r25h = (r25 + 1 < m) ? r25 + 1 : m - 1, r75h = (r75 + 1 < m) ? r75 + 1 : m - 1;
-    {
-        const int ranks[6] = {r_med_lo, r_med_hi, r25, r25h, r75, r75h};
-        wave_select_ranks<W, 6>(gf, m, keys, ranks, sel);
+    const bool any_nan = W::any(nanf);
+    double med, iqr = 0.0, mad;
+    if constexpr (KPL > 0) {
+        if (any_nan) {
+            med = qnan(); mad = qnan();
+            if (m > 1) iqr = qnan();
+        } else {
+            group_sort_values<W, KPL>(gf, m, dev);
+            // np.median: mean of the two middle elements
+            med = (r_med_lo == r_med_hi) ? dev[r_med_lo] : (dev[r_med_lo] + dev[r_med_hi]) / 2.0;
+            if (m > 1) iqr = np_lerp(dev[r75], dev[r75h], v75 - r75) - np_lerp(dev[r25], dev[r25h], v25 - r25);
+            // MAD = median(|x - med|); a non-finite median leaves NaN deviations (inf - inf) -> NaN
+            mad = (med - med == 0.0) ? mad_of_sorted(dev, m, med) : qnan();
+        }
+    } else {
+        {
+            const int ranks[6] = {r_med_lo, r_med_hi, r25, r25h, r75, r75h};
+            wave_select_ranks<W, 6>(gf, m, keys, ranks, sel);
+        }
+        // np.median: mean of the two middle elements; NaN anywhere -> NaN
+        med = (r_med_lo == r_med_hi) ? sel[0] : (sel[0] + sel[1]) / 2.0;
+        if (m > 1) {
+            const double p25 = np_lerp(sel[2], sel[3], v25 - r25);
+            const double p75 = np_lerp(sel[4], sel[5], v75 - r75);
+            iqr = p75 - p25;
+        }
+        if (any_nan) { med = qnan(); if (m > 1) iqr = qnan(); }
+        W::sync();
+        // ---- MAD = median(|x - med|)
+        for (int i = lane; i < m; i += W::LANES) dev[i] = fabs(gf[i] - med);
+        W::sync();
+        {
+            const int ranks[2] = {r_med_lo, r_med_hi};
+            wave_select_ranks<W, 2>(dev, m, keys, ranks, sel + 6);
+        }
+        mad = (r_med_lo == r_med_hi) ? sel[6] : (sel[6] + sel[7]) / 2.0;
+        if (any_nan || !(med - med == 0.0)) mad = qnan();
     }
-    // np.median: mean of the two middle elements; NaN anywhere -> NaN
-    double med = (r_med_lo == r_med_hi) ? sel[0] : (sel[0] + sel[1]) / 2.0;
-    double iqr = 0.0;
-    if (m > 1) {
-        const double p25 = np_lerp(sel[2], sel[3], v25 - r25);
-        const double p75 = np_lerp(sel[4], sel[5], v75 - r75);
-        iqr = p75 - p25;
-    }
-    if (W::any(nanf)) { med = qnan(); if (m > 1) iqr = qnan(); }
-    W::sync();
-    // ---- MAD = median(|x - med|)
-    for (int i = lane; i < m; i += W::LANES) dev[i] = fabs(gf[i] - med);
-    W::sync();
-    {
-        const int ranks[2] = {r_med_lo, r_med_hi};
-        wave_select_ranks<W, 2>(dev, m, keys, ranks, sel + 6);
-    }
-    double mad = (r_med_lo == r_med_hi) ? sel[6] : (sel[6] + sel[7]) / 2.0;
-    if (W::any(nanf)) mad = qnan();
     // ---- max slope between time-consecutive rows (statistical.py:99-113)
     double slope = -1.0;    // -1 = "no valid dt" sentinel (slopes are >= 0)
     bool slope_nan = false;
@@ -190,14 +207,28 @@ struct StatScratch {
 template <class W, class WG, int CAP>
 LCFE_FN void stat_object(const ObjLds<CAP>& L, StatScratch<CAP>& S) {
     const int lane = W::lane();
+    // sorting-network width of the band groups, uniform over the wave: 4 or 8 values per lane when the
+    // longest band fits 8 lanes x that, else rank counting
+    int mb = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const int c = L.boff[k + 1] - L.boff[k]; mb = (c > mb) ? c : mb; }
+    constexpr int GL = (WG::LANES > 1) ? WG::LANES : 8;      // the host build follows the device's choice
+    const int per_lane = (mb + GL - 1) / GL;
     for (int k = WG::group_id(); k < 6; k += WG::NGROUPS) {
         const int s = L.boff[k], m = L.boff[k + 1] - s;
-        group_statistics<WG>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel[WG::group_id()], S.dev + s, S.keys + s,
-                             S.out + 17 * k);
+        double* o = S.out + 17 * k;
+        if (per_lane <= 4)
+            group_statistics<WG, 4>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel[WG::group_id()], S.dev + s, S.keys + s, o);
+        else if (per_lane <= 8)
+            group_statistics<WG, 8>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel[WG::group_id()], S.dev + s, S.keys + s, o);
+        else
+            group_statistics<WG, 0>(L.bt + s, L.bf + s, L.be + s, m, true, S.sel[WG::group_id()], S.dev + s, S.keys + s, o);
         WG::sync();
     }
     W::sync();
-    group_statistics<W>(L.t, L.f, L.e, L.n, L.sorted != 0, S.sel[0], S.dev, S.keys, S.out + 102);
+    // all rows on the full wave: CAP / 64 values per lane up to the 512-point tier
+    constexpr int KPL_ALL = (W::LANES > 1) ? ((CAP / W::LANES <= 8) ? CAP / W::LANES : 0) : ((CAP <= 512) ? 1 : 0);
+    group_statistics<W, KPL_ALL>(L.t, L.f, L.e, L.n, L.sorted != 0, S.sel[0], S.dev, S.keys, S.out + 102);
     W::sync();
     if (lane == 0) {
         double* o = S.out;

@@ -25,6 +25,45 @@
 namespace lcfe {
 
 #if defined(__HIPCC__)
+// Value held by lane (l ^ MASK) of the same wavefront, MASK a compile-time constant < 64.  Register
+// moves (DPP) where a DPP pattern is an XOR (1, 2, 3 = quad_perm; 7 = row_half_mirror; 8 = row_ror:8;
+// 15 = row_mirror), the LDS crossbar without memory traffic otherwise (ds_swizzle inside 32 lanes,
+// ds_bpermute across the halves).
+template <int MASK>
+__device__ __forceinline__ int lane_xor_fetch(int v) {
+    static_assert(MASK > 0 && MASK < 64, "lane mask");
+    if constexpr (MASK == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    else if constexpr (MASK == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    else if constexpr (MASK == 3) return __builtin_amdgcn_update_dpp(v, v, 0x1B, 0xf, 0xf, false);
+    else if constexpr (MASK == 7) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+    else if constexpr (MASK == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    else if constexpr (MASK == 15) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    else if constexpr (MASK < 32) return __builtin_amdgcn_ds_swizzle(v, 0x1f | (MASK << 10));
+    else return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ MASK) << 2), v);
+}
+template <int MASK>
+__device__ __forceinline__ double lane_xor_fetch(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = lane_xor_fetch<MASK>((int)b), hi = lane_xor_fetch<MASK>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// IEEE minNum / maxNum as single instructions (no NaN reaches the sorting network)
+__device__ __forceinline__ double dmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double dmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+inline double dmin(double a, double b) { return (b < a) ? b : a; }
+inline double dmax(double a, double b) { return (b > a) ? b : a; }
+#endif
+
+#if defined(__HIPCC__)
 struct WaveDev {
     static constexpr int LANES = 64;
     static __device__ __forceinline__ int lane() { return threadIdx.x; }
@@ -85,6 +124,8 @@ struct WaveDev {
     }
     static __device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
     static __device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
+    template <int MASK>
+    static __device__ __forceinline__ double xfetch(double v) { return lane_xor_fetch<MASK>(v); }
 };
 #endif
 
@@ -142,6 +183,11 @@ struct GroupDev {
     }
     static __device__ __forceinline__ int prefix(unsigned long long mask) {
         return __builtin_popcountll(mask & ((1ull << lane()) - 1));
+    }
+    template <int MASK>
+    static __device__ __forceinline__ double xfetch(double v) {
+        static_assert(MASK < GS, "partner outside the lane group");
+        return lane_xor_fetch<MASK>(v);
     }
 };
 
@@ -221,6 +267,8 @@ struct WaveHost {
     static double bcast(double v, int) { return v; }
     static int bcast(int v, int) { return v; }
     static double bcast_from_first_wave(double v) { return v; }
+    template <int MASK>
+    static double xfetch(double v) { return v; }     // never reached: one lane has no partner
 };
 
 LCFE_FN int popcll(unsigned long long m) { return __builtin_popcountll(m); }
