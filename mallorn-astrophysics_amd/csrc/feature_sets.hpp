@@ -108,10 +108,14 @@ template <> struct FitPolicy<WaveDev> { using type = GroupDev<8>; };
 template <class W, int CAP>
 struct RunSet<W, SET_STAT, CAP> {
     static LCFE_FN void run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
+        LCFE_PT0();
         stage_object<W, CAP>(in, ws.obj);
+        LCFE_PT(0);
         stat_object<W, typename FitPolicy<W>::type, CAP>(ws.obj, ws.stat);
+        LCFE_PT0B();
         store_row<W>(ws.stat.out, row, STAT_NCOL);
         W::sync();
+        LCFE_PT(3);
     }
 };
 

@@ -4,8 +4,8 @@
 // persistent grid that strides over the objects.  Per feature set the object's working set
 // (staged samples, sorted views, Jacobians, Gram matrices) lives in LDS; HBM is touched once for
 // the CSR slice and once for the output row.  Objects are binned into LDS tiers by point count
-// (CAP = 128 .. 2048): each tier is one launch that skips objects outside its window, so short
-// light curves run at high occupancy and long ones still fit.
+// (CAP = 128 .. 2048) by one small kernel per call that writes an index list per tier; each tier is
+// one launch over its list, so short light curves run at high occupancy and long ones still fit.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -48,62 +48,144 @@ struct BatchView {
     int64_t n_obj;
 };
 
-// One launch = one (feature set, LDS tier): objects with lo < n <= CAP are processed, others are
-// left to the other tiers; n > hi_all (longer than the largest tier) gets NaN + status -100 from
-// the largest tier.
-// Objects are handed out through a device-side ticket counter (`ticket`, zeroed before the launch)
-// when one is supplied -- fit costs are heavy-tailed (nfev 5..2000), so a static round-robin would
-// leave most waves idle behind the unluckiest one -- else by a plain grid stride.
+// ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
+constexpr int kNumBins = 6;            // five tiers + "longer than the largest tier"
+constexpr int kBinThreads = 1024;
+struct Bins {
+    const int* lists;                  // [2 * kNumBins][n_obj]: set tiers, then GP tiers
+    const int* counts;                 // [2 * kNumBins]
+    int64_t stride;                    // n_obj
+};
+
+__device__ __forceinline__ int set_bin_of(int64_t n) {
+    return (n <= 128) ? 0 : (n <= 256) ? 1 : (n <= 512) ? 2 : (n <= 1024) ? 3 : (n <= 2048) ? 4 : 5;
+}
+constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks
+constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (512..767 rows)
+// GP window on the ROW count of the object (>= its valid points); one row of the tile storage is the
+// augmented residual row, so the caps are NP - 1.
+__device__ __forceinline__ int gp_bin_of(int64_t n) {
+    return (n <= 63) ? 0 : (n <= 111) ? 1 : (n <= 159) ? 2 : (n <= kGpMidNP - 1) ? 3 : (n <= kGpGlobalNP - 1) ? 4 : 5;
+}
+
+// One block bins 1024 consecutive objects: ballots give the rank inside a wave, an LDS scan the
+// wave's offset inside the block, one atomicAdd per (block, bin) the block's slice of the list --
+// so a list keeps file order inside every 1024-object block (CSR locality for the tier kernels).
+__global__ __launch_bounds__(kBinThreads) void bin_kernel(const int64_t* offsets, int64_t n_obj, int* lists, int* counts) {
+    __shared__ int wcount[kBinThreads / 64][2 * kNumBins];
+    __shared__ int base[2 * kNumBins];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBinThreads + threadIdx.x;
+    int bin[2] = {-1, -1}, rank[2] = {0, 0};
+    if (i < n_obj) {
+        const int64_t n = offsets[i + 1] - offsets[i];
+        bin[0] = set_bin_of(n);
+        bin[1] = gp_bin_of(n);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int b = 0; b < kNumBins; ++b) {
+            const unsigned long long m = __ballot(bin[g] == b);
+            if (bin[g] == b) rank[g] = WaveDev::prefix(m);
+            if (lane == 0) wcount[wave][g * kNumBins + b] = popcll(m);
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * kNumBins) {
+        int total = 0;
+        for (int w = 0; w < kBinThreads / 64; ++w) {
+            const int c = wcount[w][threadIdx.x];
+            wcount[w][threadIdx.x] = total;
+            total += c;
+        }
+        base[threadIdx.x] = total ? atomicAdd(&counts[threadIdx.x], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (bin[g] >= 0) {
+            const int k = g * kNumBins + bin[g];
+            lists[(int64_t)k * n_obj + base[k] + wcount[wave][k] + rank[g]] = (int)i;
+        }
+}
+
+// NaN rows + status -100 for the objects of bins [from, kNumBins) of group `g` (too long for the
+// tiers this launch sequence covers); every block of the last tier's launch takes a share.
+template <class W>
+__device__ void nan_fill_bins(const Bins& bins, int g, int from, double* out, int ld, int col0, int ncol,
+                              int32_t* status, int st_ld, int st0, int nst) {
+    for (int b = from; b < kNumBins; ++b) {
+        const int c = bins.counts[g * kNumBins + b];
+        const int* list = bins.lists + (int64_t)(g * kNumBins + b) * bins.stride;
+        for (int pos = blockIdx.x; pos < c; pos += gridDim.x) {
+            const int64_t i = list[pos];
+            fill_row_nan<W>(out + i * (int64_t)ld + col0, ncol);
+            if (status && nst)
+                for (int k = threadIdx.x; k < nst; k += blockDim.x) status[i * (int64_t)st_ld + st0 + k] = -100;
+        }
+    }
+}
+
+// One launch = one (feature set, LDS tier): the objects of the tier's index list are handed out
+// through a device-side ticket counter (zeroed once per call) -- fit costs are heavy-tailed (nfev
+// 5..2000), so a static round-robin would leave most waves idle behind the unluckiest one.  One
+// ticket = `chunk` consecutive list entries (a single counter saturates near 90 tickets/us, so the
+// cheap streaming sets take 8 objects per ticket; the fits take one); the chunk's list entries and
+// CSR offsets are fetched by its first lanes in one go.  The launch of the last tier also writes the
+// NaN rows of the objects that are too long for it (bins >= nan_from).
 template <int SET, int CAP>
-__global__ __launch_bounds__(64) void set_kernel(BatchView B, int lo, int last_tier, double* out,
+__global__ __launch_bounds__(64) void set_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out,
                                                  int ld, int col0, int32_t* status, int st_ld,
                                                  int st0, unsigned long long* ticket, int chunk) {
     __shared__ SetLds<SET, CAP> ws;
-    __shared__ long long next_obj;
+    __shared__ long long next_ticket;
     using W = WaveDev;
     const int ncol = set_ncols(SET);
     const int nst = set_nstatus(SET);
-    // one ticket = `chunk` consecutive objects (a single shared counter saturates near 90 tickets/us,
-    // so the cheap streaming sets take 8 objects per ticket; the fits take one)
-    int64_t base = (int64_t)blockIdx.x * chunk, i = base - 1;
+    const int count = bins.counts[bin];
+    const int* list = bins.lists + (int64_t)bin * bins.stride;
+    // a sparsely filled tier hands out smaller tickets, so that every wave gets several of them
+    const int per_wave = count / (4 * (int)gridDim.x);
+    chunk = (per_wave < 1) ? 1 : ((per_wave < chunk) ? per_wave : chunk);
+    LCFE_PT_INIT();
+    LCFE_PT0();
     for (;;) {
-        ++i;
-        if (i >= base + chunk || i >= B.n_obj) {
-            if (ticket) {
-                if (threadIdx.x == 0) next_obj = (long long)atomicAdd(ticket, 1ull);
-                __syncthreads();
-                base = next_obj * chunk;
-                __syncthreads();
-            } else {
-                base += (int64_t)gridDim.x * chunk;
-            }
-            i = base;
-            if (i >= B.n_obj) break;
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t base = next_ticket * chunk;
+        __syncthreads();
+        if (base >= count) break;
+        const int nk = (count - base < chunk) ? (int)(count - base) : chunk;
+        int obj_l = 0, n_l = 0;
+        long long s_l = 0;
+        if ((int)threadIdx.x < nk) {
+            obj_l = list[base + threadIdx.x];
+            s_l = B.offsets[obj_l];
+            n_l = (int)(B.offsets[obj_l + 1] - s_l);
         }
-        const int64_t s = B.offsets[i];
-        const int64_t n64 = B.offsets[i + 1] - s;
-        if (n64 <= lo) continue;
-        double* row = out + i * (int64_t)ld + col0;
-        int32_t* st = (status && nst) ? status + i * (int64_t)st_ld + st0 : nullptr;
-        if (n64 > CAP) {
-            if (last_tier) {
-                fill_row_nan<W>(row, ncol);
-                if (st) for (int k = W::lane(); k < nst; k += 64) st[k] = -100;
-            }
-            continue;
+        for (int k = 0; k < nk; ++k) {
+            const int64_t i = W::rdlane(obj_l, k);
+            const int64_t s = ((int64_t)W::rdlane((int)(s_l >> 32), k) << 32) | (unsigned int)W::rdlane((int)s_l, k);
+            const int n = W::rdlane(n_l, k);
+            double* row = out + i * (int64_t)ld + col0;
+            int32_t* st = (status && nst) ? status + i * (int64_t)st_ld + st0 : nullptr;
+            ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, n, B.z ? B.z[i] : qnan()};
+            LCFE_PT(5);
+            RunSet<W, SET, CAP>::run(in, ws, row, st);
+            LCFE_PT0B();
         }
-        ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, B.z ? B.z[i] : qnan()};
-        RunSet<W, SET, CAP>::run(in, ws, row, st);
     }
+    nan_fill_bins<W>(bins, 0, nan_from, out, ld, col0, ncol, status, st_ld, st0, nst);
+    LCFE_PT(5);
+    LCFE_PT_FLUSH();
 }
 
 int num_cus(int dev);
 
 // ---- 2-D GP: one light curve per workgroup (256/512/1024 threads by tier); Gram matrix as 16x16
 // lower-triangle tiles in LDS (NP <= 160) or, for longer light curves, in a per-workgroup slab of
-// global scratch.
-constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks
-constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (fallback for 512..767 rows)
+// global scratch.  Objects come from the tier's index list through a ticket counter (one object per
+// ticket: an L-BFGS-B run is 10^5..10^7 cycles and heavy-tailed).
 constexpr int kGpGlobalGrid = 256;
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
@@ -111,25 +193,27 @@ constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGl
 template <int NP> struct gp_threads { static constexpr int T = (NP >= 512) ? 1024 : ((NP >= 112) ? 512 : 256); };
 
 template <int NP, bool GLOBAL_K>
-__global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, int lo, int hi, int last_tier, double* out, int ld,
-                                                 int col0, int32_t* status, int st_ld, int st0, double* kscratch) {
+__global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+                                                 int col0, int32_t* status, int st_ld, int st0, double* kscratch,
+                                                 unsigned long long* ticket) {
     using W = BlockDev<gp_threads<NP>::T>;
     __shared__ GpLds<NP, W::NWAVES> S;
     __shared__ double Klds[GLOBAL_K ? 1 : gp_store_doubles(NP)];
+    __shared__ long long next_ticket;
     double* Kg = kscratch + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
-    for (int64_t i = blockIdx.x; i < B.n_obj; i += gridDim.x) {
+    const int count = bins.counts[kNumBins + bin];
+    const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t pos = next_ticket;
+        __syncthreads();
+        if (pos >= count) break;
+        const int64_t i = list[pos];
         const int64_t s = B.offsets[i];
         const int64_t n64 = B.offsets[i + 1] - s;
-        if (n64 <= lo) continue;
         double* row = out + i * (int64_t)ld + col0;
         int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
-        if (n64 > hi) {
-            if (last_tier) {
-                fill_row_nan<W>(row, GP_NCOL);
-                if (st && threadIdx.x < 4) st[threadIdx.x] = -100;
-            }
-            continue;
-        }
         ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
         if constexpr (GLOBAL_K) {
             gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
@@ -141,11 +225,13 @@ __global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, int 
         store_row<W>(S.out, row, GP_NCOL);
         __syncthreads();
     }
+    nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP_NCOL, status, st_ld, st0, 4);
 }
 
 template <int NP, bool GLOBAL_K>
-int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, int ld, int col0, int32_t* status,
-                   int st_ld, int st0, hipStream_t stream, int dev, double* kscratch) {
+int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
+                   int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, double* kscratch,
+                   unsigned long long* ticket) {
     int per_cu = 0;
     constexpr int threads = gp_threads<NP>::T;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, threads, 0));
@@ -154,16 +240,15 @@ int launch_gp_tier(const BatchView& B, int lo, int hi, int last, double* out, in
     if (GLOBAL_K && grid > kGpGlobalGrid) grid = kGpGlobalGrid;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(threads), 0, stream, B, lo, hi, last, out, ld,
-                       col0, status, st_ld, st0, kscratch);
+    hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(threads), 0, stream, B, bins, bin, nan_from,
+                       out, ld, col0, status, st_ld, st0, kscratch, ticket);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
-              int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch) {
-    // window (lo, hi] on the ROW count of the object (>= its valid points); one row of the tile
-    // storage is the augmented residual row, so the caps are NP - 1.
+int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
+              int st_ld, int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch,
+              unsigned long long* tickets) {
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
@@ -172,27 +257,24 @@ int launch_gp(const BatchView& B, int64_t max_len, double* out, int ld, int col0
     while (last < 4 && caps[last] < max_len) ++last;
     if (last >= 3 && kscratch_bytes < kGpMidBytes + kGpGlobalBytes)
         return fail_msg("lcfe_extract_device: workspace too small for the GP global tier");
-    int lo = -1;
     for (int ti = 0; ti <= last; ++ti) {
-        const int is_last = (ti == last);
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        unsigned long long* tk = tickets + SET_GP2D * 8 + ti;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp_tier<64, false>(B, lo, caps[0], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 1: rc = launch_gp_tier<112, false>(B, lo, caps[1], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 2: rc = launch_gp_tier<160, false>(B, lo, caps[2], is_last, out, ld, col0, status, st_ld, st0, stream, dev, nullptr); break;
-            case 3: rc = launch_gp_tier<kGpMidNP, true>(B, lo, caps[3], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch); break;
-            case 4: rc = launch_gp_tier<kGpGlobalNP, true>(B, lo, caps[4], is_last, out, ld, col0, status, st_ld, st0, stream, dev, kscratch + kGpMidBytes / 8); break;
+            case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
+            case 1: rc = launch_gp_tier<112, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
+            case 2: rc = launch_gp_tier<160, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
+            case 3: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, kscratch, tk); break;
+            case 4: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, kscratch + kGpMidBytes / 8, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
-        lo = caps[ti];
     }
     return 0;
 }
 
-struct Tier { int cap; };
 const int kTiers[] = {128, 256, 512, 1024, 2048};
-constexpr int kNumTiers = 5;
 constexpr int kMaxPoints = 2048;
 
 int g_num_cu[16] = {0};
@@ -208,23 +290,17 @@ int num_cus(int dev) {
 }
 
 template <int SET, int CAP>
-int launch_tier(const BatchView& B, int lo, int last, double* out, int ld, int col0, int32_t* status,
-                int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+int launch_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
+                int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, set_kernel<SET, CAP>, 64, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
-    if (grid > B.n_obj) grid = B.n_obj;
-    if (grid < 1) return 0;
     const int chunk = (SET == SET_BAZIN || SET == SET_POWERLAW) ? 1 : 8;
     if (grid * chunk > B.n_obj) grid = (B.n_obj + chunk - 1) / chunk;
-    if (ticket) {
-        // tickets 0..grid-1 are taken implicitly by the blocks' first chunk
-        HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), stream));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ticket, (int)grid, 1, stream));
-    }
-    hipLaunchKernelGGL((set_kernel<SET, CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, lo, last, out,
-                       ld, col0, status, st_ld, st0, ticket, chunk);
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((set_kernel<SET, CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, nan_from,
+                       out, ld, col0, status, st_ld, st0, ticket, chunk);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -236,29 +312,28 @@ constexpr int max_tier() {
 }
 
 template <int SET>
-int launch_set(const BatchView& B, int64_t max_len, double* out, int ld, int col0, int32_t* status,
+int launch_set(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
                int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
     // tiers needed: every tier whose window (prev_cap, cap] can contain an object, i.e. up to the
-    // first cap >= max_len; the last launched tier also NaN-fills objects longer than its cap.
+    // first cap >= max_len; the last launched tier also NaN-fills the bins of longer objects.
     int last = 0;
     while (last < max_tier<SET>() && kTiers[last] < max_len) ++last;
-    int lo = -1;   // n == 0 objects (never produced by the packer) still get a row from tier 0
     for (int ti = 0; ti <= last; ++ti) {
-        const int is_last = (ti == last);
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        unsigned long long* tk = tickets + SET * 8 + ti;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_tier<SET, 128>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 0 : nullptr); break;
-            case 1: rc = launch_tier<SET, 256>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 1 : nullptr); break;
-            case 2: rc = launch_tier<SET, 512>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 2 : nullptr); break;
-            case 3: rc = launch_tier<SET, 1024>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 3 : nullptr); break;
+            case 0: rc = launch_tier<SET, 128>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 1: rc = launch_tier<SET, 256>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 2: rc = launch_tier<SET, 512>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 3: rc = launch_tier<SET, 1024>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
             case 4:
                 if constexpr (max_tier<SET>() >= 4)
-                    rc = launch_tier<SET, 2048>(B, lo, is_last, out, ld, col0, status, st_ld, st0, stream, dev, tickets ? tickets + SET * 8 + 4 : nullptr);
+                    rc = launch_tier<SET, 2048>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk);
                 break;
         }
         if (rc) return rc;
         ++*n_launch;
-        lo = kTiers[ti];
     }
     return 0;
 }
@@ -277,6 +352,16 @@ int lcfe_debug_trf_prof(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lcfe::g_trf_prof), 64) != hipSuccess) return 1;
     unsigned long long z[8] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(lcfe::g_trf_prof), z, 64) != hipSuccess) return 1;
+    return 0;
+}
+#endif
+
+#ifdef LCFE_PHASE_PROF
+// debug builds only: read and reset the phase cycle counters
+int lcfe_debug_phase_prof(unsigned long long* out32) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(lcfe::g_phase_prof), 256) != hipSuccess) return 1;
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lcfe::g_phase_prof), z, 256) != hipSuccess) return 1;
     return 0;
 }
 #endif
@@ -324,8 +409,13 @@ const char* lcfe_colname(int mask, int64_t j) {
     return nullptr;
 }
 
-size_t lcfe_workspace_bytes(int mask, int64_t, int64_t) {
-    size_t b = 1024;
+// workspace layout: [0, 512) ticket counters (8 per set), [512, 1024) bin counts, then the
+// 2 x kNumBins index lists of n_obj int32 each (256-byte aligned total), then the GP scratch slabs
+static size_t list_bytes(int64_t n_obj) {
+    return (((size_t)(n_obj > 0 ? n_obj : 0) * 2 * kNumBins * sizeof(int)) + 255) & ~(size_t)255;
+}
+size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t) {
+    size_t b = 1024 + list_bytes(n_obj);
     if (mask & (1 << SET_GP2D)) b += kGpMidBytes + kGpGlobalBytes;
     return b;
 }
@@ -340,6 +430,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if ((mask & (1 << s)) && !set_implemented(s))
             return fail_msg("lcfe_extract_device: feature set " + std::to_string(s) + " is not built into this library");
     if (n_obj < 0 || n_points < 0 || max_len < 0) return fail_msg("lcfe_extract_device: negative size");
+    if (n_obj > 0x7fffffff - kBinThreads) return fail_msg("lcfe_extract_device: more than 2^31 objects in one batch");
     if (n_obj == 0) return 0;
     if (!d_offsets || !d_out || (n_points > 0 && (!d_t || !d_flux || !d_err || !d_band)))
         return fail_msg("lcfe_extract_device: null array");
@@ -355,10 +446,15 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         prof->bytes_in = 25 * n_points + 8 * (n_obj + 1) + (d_z ? 8 * n_obj : 0);
         prof->bytes_out = 8 * n_obj * (int64_t)ld;
     }
-    // workspace layout: [0, 1 KiB) ticket counters (8 per set), then the GP scratch slabs
-    unsigned long long* tickets = (d_workspace && workspace_bytes >= 1024) ? (unsigned long long*)d_workspace : nullptr;
-    double* gp_scratch = (d_workspace && workspace_bytes > 1024) ? (double*)((char*)d_workspace + 1024) : nullptr;
-    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - 1024 : 0;
+    const size_t lists_b = list_bytes(n_obj);
+    if (!d_workspace || workspace_bytes < 1024 + lists_b)
+        return fail_msg("lcfe_extract_device: workspace smaller than lcfe_workspace_bytes(mask, n_obj, n_points)");
+    unsigned long long* tickets = (unsigned long long*)d_workspace;
+    int* counts = (int*)((char*)d_workspace + 512);
+    int* lists = (int*)((char*)d_workspace + 1024);
+    double* gp_scratch = (workspace_bytes > 1024 + lists_b) ? (double*)((char*)d_workspace + 1024 + lists_b) : nullptr;
+    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - 1024 - lists_b : 0;
+    const Bins bins{lists, counts, n_obj};
     hipEvent_t ev[NUM_SETS + 1];
     if (prof)
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
@@ -367,18 +463,25 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     for (int s = 0; s < NUM_SETS; ++s) {
         if (!(mask & (1 << s))) continue;
         if (prof) HIP_TRY(hipEventRecord(ev[ne], stream));
+        if (ne == 0) {
+            // shared prologue (timed with the first set): zero tickets and counts, bin the objects
+            HIP_TRY(hipMemsetAsync(d_workspace, 0, 1024, stream));
+            hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((n_obj + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0,
+                               stream, d_offsets, n_obj, lists, counts);
+            HIP_TRY(hipGetLastError());
+        }
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_set<SET_STAT>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_TDE: rc = launch_set<SET_TDE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_COLOR: rc = launch_set<SET_COLOR>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_STAT: rc = launch_set<SET_STAT>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
             case SET_GP2D:
-                rc = launch_gp(B, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, gp_scratch,
-                               gp_scratch_bytes, &nl);
+                rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, gp_scratch,
+                               gp_scratch_bytes, &nl, tickets);
                 break;
         }
         if (rc) return rc;

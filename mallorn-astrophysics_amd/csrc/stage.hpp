@@ -31,25 +31,29 @@ template <class W, int CAP>
 LCFE_FN void stage_object(const ObjIn& in, ObjLds<CAP>& L) {
     const int lane = W::lane();
     const int n = in.n;
-    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    int cnt[6] = {0, 0, 0, 0, 0, 0};      // wave-uniform: ballots counted on the scalar unit
     bool ok = true;
-    for (int i = lane; i < n; i += W::LANES) {
-        double ti = in.t[i];
-        L.t[i] = ti;
-        L.f[i] = in.f[i];
-        L.e[i] = in.e[i];
-        unsigned char bb = in.b[i];
-        L.b[i] = bb;
+    for (int base = 0; base < n; base += W::LANES) {
+        const int i = base + lane;
+        int bb = 256;
+        if (i < n) {
+            const double ti = in.t[i];
+            L.t[i] = ti;
+            L.f[i] = in.f[i];
+            L.e[i] = in.e[i];
+            const unsigned char b8 = in.b[i];
+            L.b[i] = b8;
+            bb = b8;
+            if (i + 1 < n) ok = ok && (ti <= in.t[i + 1]);
+        }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cnt[k] += (bb == k);
-        if (i + 1 < n) ok = ok && (ti <= in.t[i + 1]);
+        for (int k = 0; k < 6; ++k) cnt[k] += popcll(W::ballot(bb == k));
     }
     const bool sorted = W::all(ok);
     int off = 0;
     if (lane == 0) L.boff[0] = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        cnt[k] = W::sum(cnt[k]);
         off += cnt[k];
         if (lane == 0) L.boff[k + 1] = off;
     }
@@ -223,24 +227,32 @@ LCFE_FN void group_sort_values(const double* x, int m, double* sorted) {
 
 // median(|s_i - med|) of an ascending array s[0..m) whose median is `med` (finite): the deviations of
 // the upper half [h, m) ascend, those of the lower half descend, so the two middle ranks of their
-// merge are found by a bisection on "how many come from the upper half" -- every deviation is the
-// same floating-point subtraction numpy performs, so the result is exact.  Uniform over the group.
+// merge follow from "how many of the r+1 smallest come from the upper half" = the number of
+// candidates i with upper[i] < lower[r - i] (a monotone predicate, all candidates tested at once,
+// one LDS round trip).  Every deviation is the same floating-point subtraction numpy performs, so
+// the result is exact.  Uniform over the group.
+template <class W>
 LCFE_FN double mad_of_sorted(const double* s, int m, double med) {
+    const int lane = W::lane();
     const int h = m / 2, a = m - h, b = h;
     const int r = (m - 1) / 2;                 // lower middle rank; the upper one is m / 2
-    int lo = (r + 1 - b > 0) ? r + 1 - b : 0, hi = (a < r + 1) ? a : r + 1;
-    while (lo < hi) {
-        const int i = (lo + hi) >> 1, j = r + 1 - i;
-        if (s[h + i] - med < med - s[h - j]) lo = i + 1; else hi = i;
+    const int lo = (r + 1 - b > 0) ? r + 1 - b : 0, hi = (a < r + 1) ? a : r + 1;
+    int cnt = 0;
+    for (int base = lo; base < hi; base += W::LANES) {
+        const int c = base + lane;
+        const bool in = c < hi;
+        const int ci = in ? c : lo;            // lo < hi here, so index lo is a valid candidate
+        const bool p = in && (s[h + ci] - med < med - s[h - (r + 1 - ci)]);
+        cnt += popcll(W::ballot(p));
     }
-    const int i = lo, j = r + 1 - i;
-    double v_lo = -__builtin_inf();
-    if (i > 0) v_lo = s[h + i - 1] - med;
-    if (j > 0) { const double d = med - s[h - j]; v_lo = (d > v_lo) ? d : v_lo; }
+    const int i = lo + cnt, j = r + 1 - i;
+    const double ua = s[h + ((i > 0) ? i - 1 : 0)] - med, la = med - s[(j > 0) ? h - j : 0];
+    const double ub = s[h + ((i < a) ? i : 0)] - med, lb = med - s[(j < b) ? h - 1 - j : 0];
+    double v_lo = (i > 0) ? ua : -__builtin_inf();
+    v_lo = (j > 0 && la > v_lo) ? la : v_lo;
     if (r == m / 2) return v_lo;
-    double v_hi = __builtin_inf();
-    if (i < a) v_hi = s[h + i] - med;
-    if (j < b) { const double d = med - s[h - 1 - j]; v_hi = (d < v_hi) ? d : v_hi; }
+    double v_hi = (i < a) ? ub : __builtin_inf();
+    v_hi = (j < b && lb < v_hi) ? lb : v_hi;
     return (v_lo + v_hi) / 2.0;
 }
 

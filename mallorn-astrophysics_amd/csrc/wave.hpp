@@ -271,6 +271,27 @@ struct WaveHost {
     static double xfetch(double v) { return v; }     // never reached: one lane has no partner
 };
 
+// Debug builds (-DLCFE_PHASE_PROF): cycle counters per code phase, recorded by thread 0 of a workgroup.
+#if defined(LCFE_PHASE_PROF) && defined(__HIPCC__)
+__device__ unsigned long long g_phase_prof[32];
+// per-workgroup accumulators (same-address global atomics per phase would throttle the kernel)
+__device__ __forceinline__ unsigned long long* phase_prof_lds() {
+    __shared__ unsigned long long acc[32];
+    return acc;
+}
+#define LCFE_PT0() unsigned long long pt0__ = __builtin_readcyclecounter()
+#define LCFE_PT0B() pt0__ = __builtin_readcyclecounter()
+#define LCFE_PT(slot_) do { unsigned long long pt1__ = __builtin_readcyclecounter(); if (threadIdx.x == 0) phase_prof_lds()[slot_] += pt1__ - pt0__; pt0__ = __builtin_readcyclecounter(); } while (0)
+#define LCFE_PT_INIT() do { if (threadIdx.x < 32) phase_prof_lds()[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define LCFE_PT_FLUSH() do { __syncthreads(); if (threadIdx.x < 32) atomicAdd(&g_phase_prof[threadIdx.x], phase_prof_lds()[threadIdx.x]); } while (0)
+#else
+#define LCFE_PT0() do {} while (0)
+#define LCFE_PT0B() do {} while (0)
+#define LCFE_PT_INIT() do {} while (0)
+#define LCFE_PT_FLUSH() do {} while (0)
+#define LCFE_PT(slot_) do {} while (0)
+#endif
+
 LCFE_FN int popcll(unsigned long long m) { return __builtin_popcountll(m); }
 
 // quiet NaN without relying on host/device library differences
