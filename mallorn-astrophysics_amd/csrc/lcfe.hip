@@ -15,6 +15,7 @@
 
 #include "../../include/lcfe.h"
 #include "feature_sets.hpp"
+#include "stat_lean.hpp"
 
 using namespace lcfe;
 
@@ -51,9 +52,11 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 6;            // five tiers + "longer than the largest tier"
 constexpr int kBinThreads = 1024;
+constexpr int kNumLists = 2 * kNumBins + 1;
+constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 struct Bins {
-    const int* lists;                  // [2 * kNumBins][n_obj]: set tiers, then GP tiers
-    const int* counts;                 // [2 * kNumBins]
+    int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
+    int* counts;                       // [kNumLists]
     int64_t stride;                    // n_obj
 };
 
@@ -176,6 +179,62 @@ __global__ __launch_bounds__(64) void set_kernel(BatchView B, Bins bins, int bin
         }
     }
     nan_fill_bins<W>(bins, 0, nan_from, out, ld, col0, ncol, status, st_ld, st0, nst);
+    LCFE_PT(5);
+    LCFE_PT_FLUSH();
+}
+
+// Statistics, lean layout (stat_lean.hpp) for the tiers up to 512 rows.  Same ticket scheme as
+// set_kernel; an object that does not fit the lean shape is appended to the fallback list, which a
+// set_kernel<SET_STAT, CAP> launch processes afterwards.
+// waves per SIMD the LDS footprint allows (5.6 / 9.9 / 18.4 KiB per object): the register budget follows
+template <int CAP> struct stat_lean_waves { static constexpr int N = (CAP <= 256) ? 4 : 2; };
+
+template <int CAP>
+__global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(BatchView B, Bins bins, int bin, double* out, int ld, int col0,
+                                                       unsigned long long* ticket, int chunk) {
+    __shared__ StatLeanLds<CAP> L;
+    __shared__ long long next_ticket;
+    using W = WaveDev;
+    const int count = bins.counts[bin];
+    const int* list = bins.lists + (int64_t)bin * bins.stride;
+    const int per_wave = count / (4 * (int)gridDim.x);
+    chunk = (per_wave < 1) ? 1 : ((per_wave < chunk) ? per_wave : chunk);
+    LCFE_PT_INIT();
+    LCFE_PT0();
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t base = next_ticket * chunk;
+        __syncthreads();
+        if (base >= count) break;
+        const int nk = (count - base < chunk) ? (int)(count - base) : chunk;
+        int obj_l = 0, n_l = 0;
+        long long s_l = 0;
+        if ((int)threadIdx.x < nk) {
+            obj_l = list[base + threadIdx.x];
+            s_l = B.offsets[obj_l];
+            n_l = (int)(B.offsets[obj_l + 1] - s_l);
+        }
+        for (int k = 0; k < nk; ++k) {
+            const int obj = W::rdlane(obj_l, k);
+            const int64_t s = ((int64_t)W::rdlane((int)(s_l >> 32), k) << 32) | (unsigned int)W::rdlane((int)s_l, k);
+            const int n = W::rdlane(n_l, k);
+            ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, n, qnan()};
+            LCFE_PT(5);
+            const bool lean = stat_lean_stage<CAP>(in, L);
+            LCFE_PT(0);
+            if (lean) {
+                stat_lean_object<CAP>(n, L);
+                LCFE_PT0B();
+                store_row<W>(L.out, out + (int64_t)obj * ld + col0, STAT_NCOL);
+                W::sync();
+                LCFE_PT(3);
+            } else if (threadIdx.x == 0) {
+                const int slot = atomicAdd(&bins.counts[kStatFallbackList], 1);
+                bins.lists[(int64_t)kStatFallbackList * bins.stride + slot] = obj;
+            }
+        }
+    }
     LCFE_PT(5);
     LCFE_PT_FLUSH();
 }
@@ -338,6 +397,52 @@ int launch_set(const BatchView& B, const Bins& bins, int64_t max_len, double* ou
     return 0;
 }
 
+template <int CAP>
+int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
+                     int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stat_lean_kernel<CAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((stat_lean_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0,
+                       ticket, 8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Statistics: lean kernels for the tiers up to 512 rows, the general kernel for the longer tiers,
+// for the lean kernels' fallback list and for the NaN rows of over-long objects.
+int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0,
+                hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
+    int last = 0;
+    while (last < 4 && kTiers[last] < max_len) ++last;
+    unsigned long long* tk = tickets + SET_STAT * 8;
+    for (int ti = 0; ti <= last; ++ti) {
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
+            case 1: rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
+            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
+            case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + ti); break;
+            case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + ti); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+    }
+    // fallback list of the lean tiers (+ the NaN rows when no general tier ran)
+    const int nan_from = (last <= 2) ? last + 1 : kNumBins;
+    int rc = 0;
+    if (last == 0) rc = launch_tier<SET_STAT, 128>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
+    else if (last == 1) rc = launch_tier<SET_STAT, 256>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
+    else rc = launch_tier<SET_STAT, 512>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
+    if (rc) return rc;
+    ++*n_launch;
+    return 0;
+}
+
 #include "colnames.inc"
 
 bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
@@ -410,9 +515,9 @@ const char* lcfe_colname(int mask, int64_t j) {
 }
 
 // workspace layout: [0, 512) ticket counters (8 per set), [512, 1024) bin counts, then the
-// 2 x kNumBins index lists of n_obj int32 each (256-byte aligned total), then the GP scratch slabs
+// kNumLists index lists of n_obj int32 each (256-byte aligned total), then the GP scratch slabs
 static size_t list_bytes(int64_t n_obj) {
-    return (((size_t)(n_obj > 0 ? n_obj : 0) * 2 * kNumBins * sizeof(int)) + 255) & ~(size_t)255;
+    return (((size_t)(n_obj > 0 ? n_obj : 0) * kNumLists * sizeof(int)) + 255) & ~(size_t)255;
 }
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t) {
     size_t b = 1024 + list_bytes(n_obj);
@@ -472,7 +577,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         }
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_set<SET_STAT>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, stream, dev, &nl, tickets); break;
             case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
             case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
             case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;

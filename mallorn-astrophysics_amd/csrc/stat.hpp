@@ -52,14 +52,41 @@ LCFE_FN void stat_write17(double* out17, int m, double mean, double std, double 
     out17[16] = (m > 1) ? (tmx - tmn) / (double)(m - 1) : 0.0;
 }
 
+// a group without rows (statistical.py:56-66): n_obs 0, everything else NaN
+LCFE_FN void stat_empty_group(double* out17, StatPartial* part_out) {
+    out17[0] = 0.0;
+    for (int k = 1; k < 17; ++k) out17[k] = qnan();
+    if (part_out) *part_out = StatPartial{0.0, __builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf(), 0.0, 0, 0};
+}
+
+// band-mean ratios and peak_band from the seven finished groups (one lane)
+LCFE_FN void stat_cross_band(double* o) {
+    // statistical.py:201-214: ratio of band means, NaN unless numerator is not NaN and denominator > 0
+    const double mg = o[17 * 1 + 1], mr = o[17 * 2 + 1], mi = o[17 * 3 + 1], mz = o[17 * 4 + 1];
+    o[119] = (!is_nan(mg) && mr > 0) ? mg / mr : qnan();
+    o[120] = (!is_nan(mr) && mi > 0) ? mr / mi : qnan();
+    o[121] = (!is_nan(mi) && mz > 0) ? mi / mz : qnan();
+    // :217-222 first band with the largest max among bands whose max is not NaN
+    int pb = -1;
+    double best = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double v = o[17 * k + 4];
+        if (!is_nan(v) && (pb < 0 || v > best)) { pb = k; best = v; }
+    }
+    o[122] = (double)pb;
+}
+
 // Device fast path of group_statistics for a time-sorted group of 1 <= m <= LANES * KPL rows: every
 // lane keeps its KPL fluxes (rows lane, lane + LANES, ...) in registers through the three moment
 // passes and the sorting network; the loops are unrolled with select-predication (no divergent
 // blocks), so the independent per-row chains -- LDS reads, divisions -- overlap.  Same per-lane
 // accumulation order as the generic loops below, hence the same sums.
-template <class W, int KPL>
+// GATHER (the all-rows group of the lean kernel): the rows are stored band-partitioned and
+// `pos_of[i]` is the storage position of file row i, so time-consecutive neighbours are gathered.
+template <class W, int KPL, bool GATHER = false>
 LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const double* ge, int m, double* sorted,
-                                   double* out17, StatPartial* part_out, const StatPartial* parts_in) {
+                                   double* out17, StatPartial* part_out, const StatPartial* parts_in,
+                                   const unsigned short* pos_of = nullptr) {
     const int lane = W::lane();
     constexpr int PB = (W::LANES == 64) ? 8 : 16;
     (void)PB;
@@ -194,8 +221,16 @@ LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const dou
             const int i = lane + r * W::LANES;
             const bool has = i + 1 < m;
             const int nx = has ? i + 1 : 0;
-            const double dt = gt[nx] - gt[ii[r]];
-            const double sl = fabs((gf[nx] - x[r]) / dt);
+            double dt, df;
+            if constexpr (GATHER) {
+                const int p0 = pos_of[ii[r]], p1 = pos_of[nx];
+                dt = gt[p1] - gt[p0];
+                df = gf[p1] - gf[p0];
+            } else {
+                dt = gt[nx] - gt[ii[r]];
+                df = gf[nx] - x[r];
+            }
+            const double sl = fabs(df / dt);
             const bool valid = has && dt > 0;
             slope_nan = slope_nan || (valid && is_nan(sl));
             slope = (valid && sl > slope) ? sl : slope;
@@ -223,11 +258,7 @@ LCFE_FN void group_statistics(const double* gt, const double* gf, const double* 
                               StatPartial* part_out, const StatPartial* parts_in) {
     const int lane = W::lane();
     if (m == 0) {                                    // statistical.py:56-66
-        if (lane == 0) {
-            out17[0] = 0.0;
-            for (int k = 1; k < 17; ++k) out17[k] = qnan();
-            if (part_out) *part_out = StatPartial{0.0, __builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf(), 0.0, 0, 0};
-        }
+        if (lane == 0) stat_empty_group(out17, part_out);
         return;
     }
     constexpr int PB = (W::LANES == 64) ? 8 : 16;   // phase-profile slots (debug builds)
@@ -444,22 +475,7 @@ LCFE_FN void stat_object(const ObjLds<CAP>& L, StatScratch<CAP>& S) {
                                  (L.boff[6] == L.n) ? S.part : nullptr);
     LCFE_PT(2);
     W::sync();
-    if (lane == 0) {
-        double* o = S.out;
-        // statistical.py:201-214: ratio of band means, NaN unless numerator is not NaN and denominator > 0
-        const double mg = o[17 * 1 + 1], mr = o[17 * 2 + 1], mi = o[17 * 3 + 1], mz = o[17 * 4 + 1];
-        o[119] = (!is_nan(mg) && mr > 0) ? mg / mr : qnan();
-        o[120] = (!is_nan(mr) && mi > 0) ? mr / mi : qnan();
-        o[121] = (!is_nan(mi) && mz > 0) ? mi / mz : qnan();
-        // :217-222 first band with the largest max among bands whose max is not NaN
-        int pb = -1;
-        double best = 0.0;
-        for (int k = 0; k < 6; ++k) {
-            const double v = o[17 * k + 4];
-            if (!is_nan(v) && (pb < 0 || v > best)) { pb = k; best = v; }
-        }
-        o[122] = (double)pb;
-    }
+    if (lane == 0) stat_cross_band(S.out);
     W::sync();
     LCFE_PT(4);
 }
