@@ -350,11 +350,13 @@ int num_cus(int dev) {
 
 template <int SET, int CAP>
 int launch_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
-                int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+                int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket,
+                int64_t max_grid = 1 << 30) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, set_kernel<SET, CAP>, 64, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid > max_grid) grid = max_grid;
     const int chunk = (SET == SET_BAZIN || SET == SET_POWERLAW) ? 1 : 8;
     if (grid * chunk > B.n_obj) grid = (B.n_obj + chunk - 1) / chunk;
     if (grid < 1) return 0;
@@ -432,12 +434,14 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         if (rc) return rc;
         ++*n_launch;
     }
-    // fallback list of the lean tiers (+ the NaN rows when no general tier ran)
+    // fallback list of the lean tiers (+ the NaN rows when no general tier ran): normally empty or a
+    // handful of objects, so a quarter-chip grid keeps the launch short
     const int nan_from = (last <= 2) ? last + 1 : kNumBins;
+    const int64_t fb_grid = 256;
     int rc = 0;
-    if (last == 0) rc = launch_tier<SET_STAT, 128>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
-    else if (last == 1) rc = launch_tier<SET_STAT, 256>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
-    else rc = launch_tier<SET_STAT, 512>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5);
+    if (last == 0) rc = launch_tier<SET_STAT, 128>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5, fb_grid);
+    else if (last == 1) rc = launch_tier<SET_STAT, 256>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5, fb_grid);
+    else rc = launch_tier<SET_STAT, 512>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5, fb_grid);
     if (rc) return rc;
     ++*n_launch;
     return 0;

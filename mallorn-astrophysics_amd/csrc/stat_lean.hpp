@@ -119,8 +119,14 @@ __device__ __forceinline__ void stat_lean_object(int n, StatLeanLds<CAP>& L) {
         W::sync();
         for (int kb = 0; kb < 6; ++kb) {
             const int s = L.boff[kb], m = L.boff[kb + 1] - s;
-            if (m > 64)
-                group_statistics_fast<W, CAP / 64>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, L.out + 17 * kb, &L.part[kb], nullptr);
+            double* o = L.out + 17 * kb;
+            if (m <= 64) continue;
+            if (m <= 128 || CAP <= 128)
+                group_statistics_fast<W, 2>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
+            else if (m <= 256 || CAP <= 256)
+                group_statistics_fast<W, (CAP > 128) ? 4 : 2>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
+            else
+                group_statistics_fast<W, CAP / 64>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
         }
     }
     W::sync();
