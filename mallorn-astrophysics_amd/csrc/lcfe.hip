@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void set_kernel(BatchView B, Bins bins, int bin
 // set_kernel; an object that does not fit the lean shape is appended to the fallback list, which a
 // set_kernel<SET_STAT, CAP> launch processes afterwards.
 // waves per SIMD the LDS footprint allows (5.6 / 9.9 / 18.4 KiB per object): the register budget follows
-template <int CAP> struct stat_lean_waves { static constexpr int N = (CAP <= 256) ? 4 : 2; };
+template <int CAP> struct stat_lean_waves { static constexpr int N = (CAP <= 128) ? 4 : ((CAP <= 256) ? 3 : 2); };
 
 template <int CAP>
 __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(BatchView B, Bins bins, int bin, double* out, int ld, int col0,
