@@ -37,7 +37,7 @@ template <> struct gp_is_lds_ptr<lds_double*> { static constexpr bool value = tr
 
 // pivot-block width of the sweep: 8 for the LDS tiers and the 768-point fallback, 16 for the
 // 512-point global-scratch tier (half as many block steps, each with four MFMAs per tile)
-template <int NP> struct gp_block { static constexpr int B = (NP == 512) ? 16 : 8; };
+template <int NP> struct gp_block { static constexpr int B = (NP == 512 || NP == 240) ? 16 : 8; };
 
 // Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
 // doubles) lives in LDS for the small tiers and in a per-workgroup slab of global scratch otherwise.

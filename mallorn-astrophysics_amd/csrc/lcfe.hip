@@ -50,7 +50,7 @@ struct BatchView {
 };
 
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
-constexpr int kNumBins = 6;            // five tiers + "longer than the largest tier"
+constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
 constexpr int kNumLists = 2 * kNumBins + 1;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
@@ -61,14 +61,15 @@ struct Bins {
 };
 
 __device__ __forceinline__ int set_bin_of(int64_t n) {
-    return (n <= 128) ? 0 : (n <= 256) ? 1 : (n <= 512) ? 2 : (n <= 1024) ? 3 : (n <= 2048) ? 4 : 5;
+    return (n <= 128) ? 0 : (n <= 256) ? 1 : (n <= 512) ? 2 : (n <= 1024) ? 3 : (n <= 2048) ? 4 : 6;
 }
-constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks
+constexpr int kGpSmallNP = 240;     // matrix in global scratch, 16-wide pivot blocks, two 512-thread workgroups per CU
+constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks, one 1024-thread workgroup per CU
 constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (512..767 rows)
 // GP window on the ROW count of the object (>= its valid points); one row of the tile storage is the
 // augmented residual row, so the caps are NP - 1.
 __device__ __forceinline__ int gp_bin_of(int64_t n) {
-    return (n <= 63) ? 0 : (n <= 111) ? 1 : (n <= 159) ? 2 : (n <= kGpMidNP - 1) ? 3 : (n <= kGpGlobalNP - 1) ? 4 : 5;
+    return (n <= 63) ? 0 : (n <= 111) ? 1 : (n <= 159) ? 2 : (n <= kGpSmallNP - 1) ? 3 : (n <= kGpMidNP - 1) ? 4 : (n <= kGpGlobalNP - 1) ? 5 : 6;
 }
 
 // One block bins 1024 consecutive objects: ballots give the rank inside a wave, an LDS scan the
@@ -246,10 +247,13 @@ int num_cus(int dev);
 // global scratch.  Objects come from the tier's index list through a ticket counter (one object per
 // ticket: an L-BFGS-B run is 10^5..10^7 cycles and heavy-tailed).
 constexpr int kGpGlobalGrid = 256;
+constexpr int kGpSmallGrid = 512;
+constexpr size_t kGpSmallBytes = (size_t)kGpSmallGrid * gp_store_doubles(kGpSmallNP) * 8;
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
 template <int NP> struct gp_threads { static constexpr int T = (NP >= 512) ? 1024 : ((NP >= 112) ? 512 : 256); };
+template <int NP> struct gp_grid_cap { static constexpr int G = (NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid; };
 
 template <int NP, bool GLOBAL_K>
 __global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
@@ -296,7 +300,7 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_kernel<NP, GLOBAL_K>, threads, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
-    if (GLOBAL_K && grid > kGpGlobalGrid) grid = kGpGlobalGrid;
+    if (GLOBAL_K && grid > gp_grid_cap<NP>::G) grid = gp_grid_cap<NP>::G;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
     hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(threads), 0, stream, B, bins, bin, nan_from,
@@ -311,11 +315,14 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
-    const int caps[5] = {63, 111, 159, kGpMidNP - 1, kGpGlobalNP - 1};
+    const int caps[6] = {63, 111, 159, kGpSmallNP - 1, kGpMidNP - 1, kGpGlobalNP - 1};
     int last = 0;
-    while (last < 4 && caps[last] < max_len) ++last;
-    if (last >= 3 && kscratch_bytes < kGpMidBytes + kGpGlobalBytes)
-        return fail_msg("lcfe_extract_device: workspace too small for the GP global tier");
+    while (last < 5 && caps[last] < max_len) ++last;
+    if (last >= 3 && kscratch_bytes < kGpSmallBytes + kGpMidBytes + kGpGlobalBytes)
+        return fail_msg("lcfe_extract_device: workspace too small for the GP global tiers");
+    double* k_small = kscratch;
+    double* k_mid = kscratch + kGpSmallBytes / 8;
+    double* k_glob = k_mid + kGpMidBytes / 8;
     for (int ti = 0; ti <= last; ++ti) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
         unsigned long long* tk = tickets + SET_GP2D * 8 + ti;
@@ -324,8 +331,9 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
             case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
             case 1: rc = launch_gp_tier<112, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
             case 2: rc = launch_gp_tier<160, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
-            case 3: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, kscratch, tk); break;
-            case 4: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, kscratch + kGpMidBytes / 8, tk); break;
+            case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_small, tk); break;
+            case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_mid, tk); break;
+            case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_glob, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
@@ -525,7 +533,7 @@ static size_t list_bytes(int64_t n_obj) {
 }
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t) {
     size_t b = 1024 + list_bytes(n_obj);
-    if (mask & (1 << SET_GP2D)) b += kGpMidBytes + kGpGlobalBytes;
+    if (mask & (1 << SET_GP2D)) b += kGpSmallBytes + kGpMidBytes + kGpGlobalBytes;
     return b;
 }
 
