@@ -137,8 +137,12 @@ __device__ void nan_fill_bins(const Bins& bins, int g, int from, double* out, in
 // cheap streaming sets take 8 objects per ticket; the fits take one); the chunk's list entries and
 // CSR offsets are fetched by its first lanes in one go.  The launch of the last tier also writes the
 // NaN rows of the objects that are too long for it (bins >= nan_from).
+// minimum waves per SIMD the register allocation must leave room for: the bounded fits are long
+// dependent fp64 chains, so a second wave per SIMD matters more than keeping every value in a register
+template <int SET> struct set_waves { static constexpr int N = (SET == SET_BAZIN || SET == SET_POWERLAW) ? 2 : 1; };
+
 template <int SET, int CAP>
-__global__ __launch_bounds__(64) void set_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out,
+__global__ __launch_bounds__(64, set_waves<SET>::N) void set_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out,
                                                  int ld, int col0, int32_t* status, int st_ld,
                                                  int st0, unsigned long long* ticket, int chunk) {
     __shared__ SetLds<SET, CAP> ws;
