@@ -59,6 +59,49 @@ def test_lds_tiers_and_long_objects(name):
     assert np.isnan(got[n_ok:]).all()
 
 
+def test_statistics_band_shapes():
+    """Band layouts that take different routes through the lean statistics kernel: bands of up to 32
+    / 64 rows (8-lane groups, 4 / 8 values per lane), longer bands (full-wave passes sized by the
+    band), empty bands, a NaN flux inside a long band, and objects handed to the general kernel
+    (unknown band code, rows out of time order) in every lean tier."""
+    rng = np.random.default_rng(21)
+    objs = []
+
+    def add(counts, nan_at=None, unknown=False, shuffle=False):
+        n = int(sum(counts))
+        t = np.sort(59000 + rng.uniform(0, 600, n))
+        b = rng.permutation(np.repeat(np.arange(6), counts)).astype(np.int64)
+        f = 25 * np.exp(-0.5 * ((t - 59250) / 60) ** 2) * (1 + 0.2 * b) + rng.normal(0, 2, n)
+        e = rng.uniform(0.5, 2.0, n)
+        if nan_at is not None:
+            f[np.flatnonzero(b == nan_at)[3]] = np.nan
+        if unknown:
+            b[rng.choice(n, 3, replace=False)] = 255
+        if shuffle:
+            p = rng.permutation(n)
+            t, f, e, b = t[p], f[p], e[p], b[p]
+        objs.append((t, f, e, b))
+
+    add([10, 20, 32, 31, 5, 0])            # all bands <= 32
+    add([0, 33, 64, 12, 0, 1])             # bands <= 64
+    add([3, 65, 20, 20, 10, 2])            # one band on the full wave, tier 128
+    add([0, 0, 128, 0, 0, 0])              # single band, n = 128
+    add([5, 129, 70, 30, 10, 12])          # bands of 129 and 70 rows, tier 256
+    add([0, 0, 0, 256, 0, 0])              # single band, n = 256
+    add([40, 257, 90, 60, 33, 32])         # band > 256 rows, tier 512
+    add([85, 85, 85, 85, 86, 86])          # n = 512, every band on the full wave
+    add([3, 65, 20, 20, 10, 2], nan_at=1)  # NaN inside a long band
+    add([10, 20, 30, 31, 5, 4], nan_at=2)
+    add([10, 20, 30, 31, 5, 4], unknown=True)      # general kernel, CAP 128
+    add([20, 60, 70, 40, 5, 5], shuffle=True)      # general kernel, CAP 256
+    add([50, 100, 100, 80, 40, 30], unknown=True, shuffle=True)   # general kernel, CAP 512
+    lc = synth.from_objects(objs)
+    got = extract_csr("stat", lc)
+    ref = oracle.extract("stat", lc)
+    bad = parity.compare(got, ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+
+
 def test_unsorted_rows_match(golden_inputs):
     """Shuffling the rows of every object must not change the statistics (sort paths on device)."""
     rng = np.random.default_rng(11)
