@@ -48,7 +48,10 @@ enum {
 #define LCFE_MASK_ALL ((1 << LCFE_NUM_SETS) - 1)
 
 /* Per-call profile, filled when a non-NULL pointer is passed.  kernel_ms[s] is the HIP-event time
- * of feature set s's kernel(s) on the stream they were launched on. */
+ * of feature set s's kernel(s) on the stream they were launched on.  The statistics set (with the
+ * shared binning prologue) runs alone; the other sets run concurrently on internal side streams
+ * forked from / joined into the caller's stream, so their times overlap (environment variable
+ * LCFE_SERIAL=1 serialises them for profiling). */
 typedef struct lcfe_stats {
     double kernel_ms[LCFE_NUM_SETS];
     double h2d_ms;          /* host-buffer entry point only */

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -139,10 +140,11 @@ __device__ void nan_fill_bins(const Bins& bins, int g, int from, double* out, in
 // NaN rows of the objects that are too long for it (bins >= nan_from).
 // minimum waves per SIMD the register allocation must leave room for: the bounded fits are long
 // dependent fp64 chains, so a second wave per SIMD matters more than keeping every value in a register
-template <int SET> struct set_waves { static constexpr int N = (SET == SET_BAZIN || SET == SET_POWERLAW) ? 2 : 1; };
+// (only the 128-row tier: the larger tiers are limited to one wave per SIMD by their LDS footprint anyway)
+template <int SET, int CAP> struct set_waves { static constexpr int N = ((SET == SET_BAZIN || SET == SET_POWERLAW) && CAP <= 128) ? 2 : 1; };
 
 template <int SET, int CAP>
-__global__ __launch_bounds__(64, set_waves<SET>::N) void set_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out,
+__global__ __launch_bounds__(64, (set_waves<SET, CAP>::N)) void set_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out,
                                                  int ld, int col0, int32_t* status, int st_ld,
                                                  int st0, unsigned long long* ticket, int chunk) {
     __shared__ SetLds<SET, CAP> ws;
@@ -314,8 +316,8 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
 }
 
 int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
-              int st_ld, int st0, hipStream_t stream, int dev, double* kscratch, size_t kscratch_bytes, int* n_launch,
-              unsigned long long* tickets) {
+              int st_ld, int st0, hipStream_t stream, hipStream_t stream2, int dev, double* kscratch,
+              size_t kscratch_bytes, int* n_launch, unsigned long long* tickets) {
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
@@ -327,17 +329,20 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     double* k_small = kscratch;
     double* k_mid = kscratch + kGpSmallBytes / 8;
     double* k_glob = k_mid + kGpMidBytes / 8;
-    for (int ti = 0; ti <= last; ++ti) {
+    // longest objects first, tiers alternating between two streams: the heavy-tailed end of one tier
+    // (single objects of up to 50 ms) overlaps with the start of the next
+    for (int ti = last, pos = 0; ti >= 0; --ti, ++pos) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
         unsigned long long* tk = tickets + SET_GP2D * 8 + ti;
+        hipStream_t q = (pos & 1) ? stream2 : stream;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
-            case 1: rc = launch_gp_tier<112, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
-            case 2: rc = launch_gp_tier<160, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, nullptr, tk); break;
-            case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_small, tk); break;
-            case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_mid, tk); break;
-            case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, k_glob, tk); break;
+            case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
+            case 1: rc = launch_gp_tier<112, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
+            case 2: rc = launch_gp_tier<160, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
+            case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_small, tk); break;
+            case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_mid, tk); break;
+            case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_glob, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
@@ -463,6 +468,21 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
 
 bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
 
+// Non-blocking side streams per device, created on first use and kept for the life of the process.
+constexpr int kSideStreams = 3;
+hipStream_t g_side[16][kSideStreams];
+bool g_side_ready[16] = {false};
+int side_streams(int dev, hipStream_t* out) {
+    if (dev < 0 || dev >= 16) return 1;
+    if (!g_side_ready[dev]) {
+        for (int k = 0; k < kSideStreams; ++k)
+            if (hipStreamCreateWithFlags(&g_side[dev][k], hipStreamNonBlocking) != hipSuccess) return 1;
+        g_side_ready[dev] = true;
+    }
+    for (int k = 0; k < kSideStreams; ++k) out[k] = g_side[dev][k];
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -576,50 +596,99 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     double* gp_scratch = (workspace_bytes > 1024 + lists_b) ? (double*)((char*)d_workspace + 1024 + lists_b) : nullptr;
     const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - 1024 - lists_b : 0;
     const Bins bins{lists, counts, n_obj};
-    hipEvent_t ev[NUM_SETS + 1];
+    // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
+    // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
+    // remaining sets are enqueued on side streams forked from the caller's stream and joined back
+    // into it: the heavy-tailed end of one kernel is filled by the workgroups of another, and the
+    // register-bound fit kernels (1-2 waves per SIMD) share the SIMDs with each other.
+    // LCFE_SERIAL=1 keeps everything on the caller's stream (per-set times then do not overlap).
+    static const bool serial = [] { const char* e = getenv("LCFE_SERIAL"); return e && e[0] == '1'; }();
+    hipStream_t side[kSideStreams];
+    const bool fork = !serial && side_streams(dev, side) == 0;
+    // stream of each set: GP (the longest) stays on the caller's stream
+    auto stream_of = [&](int s) -> hipStream_t {
+        if (!fork) return stream;
+        switch (s) {
+            case SET_BAZIN: return side[0];
+            case SET_POWERLAW: return side[1];
+            case SET_TDE: case SET_COLOR: case SET_SHAPE: case SET_PHYSICS: return side[2];
+            default: return stream;
+        }
+    };
+    hipEvent_t ev0[NUM_SETS], ev1[NUM_SETS];
     if (prof)
-        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        for (int k = 0; k < NUM_SETS; ++k) { HIP_TRY(hipEventCreate(&ev0[k])); HIP_TRY(hipEventCreate(&ev1[k])); }
+    hipEvent_t forked = nullptr;
+    bool side_used[kSideStreams] = {false, false, false};
     int col0 = 0, st0 = 0, ne = 0;
-    int used[NUM_SETS];
     for (int s = 0; s < NUM_SETS; ++s) {
         if (!(mask & (1 << s))) continue;
-        if (prof) HIP_TRY(hipEventRecord(ev[ne], stream));
         if (ne == 0) {
             // shared prologue (timed with the first set): zero tickets and counts, bin the objects
+            if (prof) HIP_TRY(hipEventRecord(ev0[s], stream));
             HIP_TRY(hipMemsetAsync(d_workspace, 0, 1024, stream));
             hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((n_obj + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0,
                                stream, d_offsets, n_obj, lists, counts);
             HIP_TRY(hipGetLastError());
         }
+        hipStream_t q = stream_of(s);
+        if (fork && s != SET_STAT && !forked) {
+            HIP_TRY(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(forked, stream));
+        }
+        if (q != stream) {
+            const int k = (q == side[0]) ? 0 : (q == side[1]) ? 1 : 2;
+            if (!side_used[k]) { HIP_TRY(hipStreamWaitEvent(q, forked, 0)); side_used[k] = true; }
+        }
+        if (prof && ne != 0) HIP_TRY(hipEventRecord(ev0[s], q));
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, stream, dev, &nl, tickets); break;
-            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
-            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, &nl, tickets); break;
+            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets); break;
+            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_GP2D:
-                rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, stream, dev, gp_scratch,
+                if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }
+                rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, fork ? side[2] : q, dev, gp_scratch,
                                gp_scratch_bytes, &nl, tickets);
+                // the set's stop event (prof) is recorded on q: make q wait for the tiers on the second stream
+                if (fork) {
+                    hipEvent_t half;
+                    HIP_TRY(hipEventCreateWithFlags(&half, hipEventDisableTiming));
+                    HIP_TRY(hipEventRecord(half, side[2]));
+                    HIP_TRY(hipStreamWaitEvent(q, half, 0));
+                    (void)hipEventDestroy(half);
+                }
                 break;
         }
         if (rc) return rc;
-        if (prof) prof->launches[s] = nl;
-        used[ne++] = s;
+        if (prof) { HIP_TRY(hipEventRecord(ev1[s], q)); prof->launches[s] = nl; }
+        ++ne;
         col0 += set_ncols(s);
         st0 += set_nstatus(s);
     }
+    // join the side streams back into the caller's stream
+    for (int k = 0; k < kSideStreams; ++k) {
+        if (!side_used[k]) continue;
+        hipEvent_t done;
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done, side[k]));
+        HIP_TRY(hipStreamWaitEvent(stream, done, 0));
+        (void)hipEventDestroy(done);       // released once the recorded work has completed
+    }
+    if (forked) (void)hipEventDestroy(forked);
     if (prof) {
-        HIP_TRY(hipEventRecord(ev[ne], stream));
-        HIP_TRY(hipEventSynchronize(ev[ne]));
-        for (int k = 0; k < ne; ++k) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int s = 0; s < NUM_SETS; ++s) {
+            if (!(mask & (1 << s))) continue;
             float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-            prof->kernel_ms[used[k]] = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev0[s], ev1[s]));
+            prof->kernel_ms[s] = ms;
         }
-        for (auto& e : ev) (void)hipEventDestroy(e);
+        for (int k = 0; k < NUM_SETS; ++k) { (void)hipEventDestroy(ev0[k]); (void)hipEventDestroy(ev1[k]); }
     }
     return 0;
 }
