@@ -261,8 +261,12 @@ constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGl
 template <int NP> struct gp_threads { static constexpr int T = (NP >= 512) ? 1024 : ((NP >= 112) ? 512 : 256); };
 template <int NP> struct gp_grid_cap { static constexpr int G = (NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid; };
 
+// waves per SIMD to leave room for: the 64- and 112-row tiers fit two or more workgroups per CU in LDS,
+// so their register budget is halved (the L-BFGS-B driver spills a little, the sweep does not)
+template <int NP> struct gp_waves { static constexpr int N = (NP <= 112 || NP == 240) ? 4 : ((gp_threads<NP>::T == 1024) ? 4 : 2); };
+
 template <int NP, bool GLOBAL_K>
-__global__ __launch_bounds__(gp_threads<NP>::T) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+__global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch,
                                                  unsigned long long* ticket) {
     using W = BlockDev<gp_threads<NP>::T>;
