@@ -37,6 +37,20 @@ def load_lightcurves(split: str = "train", data_path: Optional[Path] = None) -> 
     return pd.concat(frames, ignore_index=True)
 
 
+def load_lightcurves_csr(split: str = "train", data_path: Optional[Path] = None, n_threads: int = 0):
+    """The split files of ``load_lightcurves`` straight into the CSR batch the GPU path takes, without the
+    DataFrame: ``(csr, object_ids)`` equal to ``pack_lightcurves(load_lightcurves(split))`` bit for bit
+    (multi-threaded C++ reader, ``utils/ingest.py`` / ``include/lcfe_ingest.h``)."""
+    from .ingest import read_lightcurves_csr
+
+    data_path = get_data_path() if data_path is None else Path(data_path)
+    paths = [data_path / f"split_{i:02d}" / f"{split}_full_lightcurves.csv" for i in range(1, 21)]
+    paths = [p for p in paths if p.exists()]
+    if not paths:
+        raise FileNotFoundError(f"No {split} lightcurve files found")
+    return read_lightcurves_csr(paths, n_threads=n_threads)
+
+
 def load_all_data(data_path: Optional[Path] = None) -> dict:
     data_path = get_data_path() if data_path is None else Path(data_path)
     train_meta, test_meta = load_metadata(data_path)
