@@ -184,7 +184,7 @@ LCFE_FN void jacobi_svd(const TriFactor<N>& T, const Vec<N>& q, double sv[N], do
                     b += W[i][r] * W[i][r];
                     c += W[i][p] * W[i][r];
                 }
-                if (c != 0.0 && fabs(c) > 1e-15 * sqrt(a * b)) {
+                if (c != 0.0 && c * c > 1e-30 * (a * b)) {       // |c| > 1e-15 sqrt(a b), without the square root
                     rotated = true;
                     const double zeta = (b - a) / (2.0 * c);
                     const double tt = ((zeta >= 0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
