@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -476,8 +477,10 @@ bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
 constexpr int kSideStreams = 3;
 hipStream_t g_side[16][kSideStreams];
 bool g_side_ready[16] = {false};
+std::mutex g_side_mutex;
 int side_streams(int dev, hipStream_t* out) {
     if (dev < 0 || dev >= 16) return 1;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
     if (!g_side_ready[dev]) {
         for (int k = 0; k < kSideStreams; ++k)
             if (hipStreamCreateWithFlags(&g_side[dev][k], hipStreamNonBlocking) != hipSuccess) return 1;
@@ -619,10 +622,20 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             default: return stream;
         }
     };
-    hipEvent_t ev0[NUM_SETS], ev1[NUM_SETS];
+    // events are destroyed on every exit path (an event that was recorded is released by the runtime once
+    // the recorded work has completed)
+    struct Events {
+        hipEvent_t ev0[NUM_SETS] = {}, ev1[NUM_SETS] = {}, forked = nullptr;
+        ~Events() {
+            for (int k = 0; k < NUM_SETS; ++k) { if (ev0[k]) (void)hipEventDestroy(ev0[k]); if (ev1[k]) (void)hipEventDestroy(ev1[k]); }
+            if (forked) (void)hipEventDestroy(forked);
+        }
+    } E;
+    hipEvent_t (&ev0)[NUM_SETS] = E.ev0;
+    hipEvent_t (&ev1)[NUM_SETS] = E.ev1;
+    hipEvent_t& forked = E.forked;
     if (prof)
         for (int k = 0; k < NUM_SETS; ++k) { HIP_TRY(hipEventCreate(&ev0[k])); HIP_TRY(hipEventCreate(&ev1[k])); }
-    hipEvent_t forked = nullptr;
     bool side_used[kSideStreams] = {false, false, false};
     int col0 = 0, st0 = 0, ne = 0;
     for (int s = 0; s < NUM_SETS; ++s) {
@@ -683,7 +696,6 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         HIP_TRY(hipStreamWaitEvent(stream, done, 0));
         (void)hipEventDestroy(done);       // released once the recorded work has completed
     }
-    if (forked) (void)hipEventDestroy(forked);
     if (prof) {
         HIP_TRY(hipStreamSynchronize(stream));
         for (int s = 0; s < NUM_SETS; ++s) {
@@ -692,7 +704,6 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             HIP_TRY(hipEventElapsedTime(&ms, ev0[s], ev1[s]));
             prof->kernel_ms[s] = ms;
         }
-        for (int k = 0; k < NUM_SETS; ++k) { (void)hipEventDestroy(ev0[k]); (void)hipEventDestroy(ev1[k]); }
     }
     return 0;
 }
