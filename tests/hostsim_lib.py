@@ -13,8 +13,10 @@ def lib():
     global _lib
     if _lib is None:
         d = os.path.join(HERE, "hostsim")
-        subprocess.run(["make", "-s", "-C", d, "libhostsim.so"], check=True)
-        _lib = ctypes.CDLL(os.path.join(d, "libhostsim.so"))
+        # HOSTSIM_SANITIZE=1: the AddressSanitizer/UBSan build (run pytest with LD_PRELOAD=libasan.so)
+        name = "libhostsim_asan.so" if os.environ.get("HOSTSIM_SANITIZE") == "1" else "libhostsim.so"
+        subprocess.run(["make", "-s", "-C", d, name], check=True)
+        _lib = ctypes.CDLL(os.path.join(d, name))
         _lib.hostsim_extract.restype = ctypes.c_int
     return _lib
 
