@@ -125,16 +125,29 @@ def main():
     # every rank draws its own shard of the synthetic survey (objects are independent)
     lc = synth.make_lightcurves(a.objects, seed=a.seed + rank)
     batch = DeviceBatch(lc, z=lc["z"], device=local)
-    out = torch.empty((a.objects, ncol), dtype=torch.float64, device=batch.device)
+    # two output buffers: the RCCL gather of step k (its own stream) overlaps the kernels of step k+1
+    outs = [torch.empty((a.objects, ncol), dtype=torch.float64, device=batch.device) for _ in range(2)]
+    out = outs[0]
     gathered = [torch.empty_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
+    pending = [None, None]
+    counter = [0]
 
     def step(prof=False):
-        r = batch.run(mask, out=out, prof=prof)
+        b = counter[0] & 1
+        counter[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()                 # the buffer's previous gather has to be done before it is rewritten
+            pending[b] = None
+        r = batch.run(mask, out=outs[b], prof=prof)
         if use_dist:
-            dist.gather(out, gathered, dst=0)
+            pending[b] = dist.gather(outs[b], gathered, dst=0, async_op=True)
         return r[2] if prof else None
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
