@@ -3,9 +3,11 @@
 // PARITY UNPINNED vs the real george, which is not installed anywhere in the build).
 //
 // One light curve per workgroup.  The N x N Gram matrix (N = valid points of all bands) is kept as
-// a packed lower triangle in LDS (fp64; N <= GP_CAP) and goes Gram -> Cholesky factor -> L^-1 ->
-// K^-1 in place; every L-BFGS-B evaluation needs all four (log-likelihood from L, gradient from
-// K^-1).  No MFMA: the matrices are a few hundred rows and the work is latency/LDS-bound.
+// 16 x 16 lower-triangle tiles (fp64) in LDS or, for longer light curves, in a per-workgroup slab of
+// global scratch, and is turned in place into -K^-1 by a blocked symmetric sweep whose row weights
+// and rank-8/16 tile updates run on the fp64 MFMA (v_mfma_f64_16x16x4_f64); the sweep also yields
+// log|K| and alpha = K^-1 r (augmented row), so every L-BFGS-B evaluation -- log-likelihood and
+// analytic gradient -- costs one sweep plus one pass over the tiles.
 #pragma once
 #include "color.hpp"     // compute_color
 #include "fits.hpp"      // wave_median

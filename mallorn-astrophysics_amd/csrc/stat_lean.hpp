@@ -56,11 +56,10 @@ __device__ __forceinline__ bool stat_lean_stage(const ObjIn& in, StatLeanLds<CAP
 #pragma unroll
         for (int k = 0; k < 6; ++k) cnt[k] += popcll(W::ballot(b[r] == k));
     }
-    int off[7], most = 0;
+    int off[7];
     off[0] = 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { off[k + 1] = off[k] + cnt[k]; most = (cnt[k] > most) ? cnt[k] : most; }
-    (void)most;
+    for (int k = 0; k < 6; ++k) off[k + 1] = off[k] + cnt[k];
     if (!W::all(ordered && known)) return false;
     if (lane == 0) {
 #pragma unroll
