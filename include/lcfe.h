@@ -96,7 +96,9 @@ int lcfe_extract(int mask, int device, int64_t n_obj, const int64_t* offsets, co
  * returns without synchronising unless `prof` is non-NULL (event times need the stream drained).
  *   max_len    an upper bound of the number of points of any object (selects the LDS tier;
  *              objects longer than the largest tier get NaN rows and status -100)
- *   workspace  device scratch of at least lcfe_workspace_bytes(mask, n_obj, n_points) bytes
+ *   workspace  device scratch of at least lcfe_workspace_bytes(mask, n_obj, n_points) bytes (ticket
+ *              counters, per-tier index lists, GP scratch); owned by the call until its work on
+ *              `stream` has completed -- concurrent calls need separate workspaces
  */
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points);
 int lcfe_extract_device(int mask, int device, void* stream, int64_t n_obj, int64_t n_points,
