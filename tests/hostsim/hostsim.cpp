@@ -84,3 +84,25 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
         default: return 1;
     }
 }
+
+// ---- bounded L-BFGS-B (csrc/lbfgsb_box.hpp) with the objective supplied by the caller: the test
+// drives it with the same Python function it hands to scipy.optimize.minimize.
+#include "../../mallorn-astrophysics_amd/csrc/lbfgsb_box.hpp"
+
+typedef void (*hostsim_fg_t)(const double* x, double* f, double* g);
+
+extern "C" int hostsim_lbfgsb_box3(double* x, const double* lo, const double* hi, hostsim_fg_t fg, int maxiter,
+                                   int maxfun, double factr, double pgtol, double* f_out, int* n_iter, int* n_eval,
+                                   double* trace, int trace_cap) {
+    double Sm[10][3], Ym[10][3];
+    double xx[3] = {x[0], x[1], x[2]}, f = 0;
+    int nt = 0;
+    auto ev = [&](const double* p, double& fv, double* gv) {
+        fg(p, &fv, gv);
+        if (trace && nt < trace_cap) { trace[4 * nt] = p[0]; trace[4 * nt + 1] = p[1]; trace[4 * nt + 2] = p[2]; trace[4 * nt + 3] = fv; ++nt; }
+    };
+    const int rc = lcfe::lbfgsb_box_minimize<3, 10>(xx, lo, hi, f, ev, maxiter, maxfun, factr, pgtol, 20, *n_iter, *n_eval, Sm, Ym);
+    for (int i = 0; i < 3; ++i) x[i] = xx[i];
+    *f_out = f;
+    return rc;
+}
