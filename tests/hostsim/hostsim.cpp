@@ -85,6 +85,38 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
     }
 }
 
+// ---- per-band 1-D GP (csrc/gp1d.hpp): the four bands g, r, i, z of every object, one after the other
+#include "../../mallorn-astrophysics_amd/csrc/gp1d.hpp"
+
+extern "C" int hostsim_gp1d(int64_t n_obj, const int64_t* offsets, const double* t, const double* flux, const double* err,
+                            const uint8_t* band, double* out, int32_t* status) {
+    using W = WaveHost;
+    constexpr int NP = 256;
+    auto obj = std::make_unique<ObjLds<HOSTSIM_CAP>>();
+    auto ws = std::make_unique<GpLds<NP, 1>>();
+    std::vector<double> K((size_t)gp_store_doubles(NP));
+    for (int64_t i = 0; i < n_obj; ++i) {
+        const int64_t s = offsets[i];
+        const int n = (int)(offsets[i + 1] - s);
+        double* o = out + i * GP1D_NCOL;
+        for (int k = 0; k < GP1D_NCOL; ++k) o[k] = qnan();
+        if (n > HOSTSIM_CAP) continue;
+        ObjIn in{t + s, flux + s, err + s, band + s, n, qnan()};
+        stage_object<W, HOSTSIM_CAP>(in, *obj);
+        bool fitted[4];
+        for (int j = 0; j < 4; ++j) {
+            const int b = j + 1;                                   // g, r, i, z
+            const int bs = obj->boff[b], m = obj->boff[b + 1] - bs;
+            fitted[j] = m >= 5;
+            gp1d_band<W, NP>(obj->bt + bs, obj->bf + bs, obj->be + bs, m, *ws,
+                             [&](const double* x, int nn, double& f, double* g) { gp1d_eval<W, NP, double*>(x, nn, *ws, K.data(), f, g); },
+                             o + 4 * j, status ? status + i * GP1D_NSTATUS + j : nullptr);
+        }
+        gp1d_cross_band(o, fitted);
+    }
+    return 0;
+}
+
 // ---- bounded L-BFGS-B (csrc/lbfgsb_box.hpp) with the objective supplied by the caller: the test
 // drives it with the same Python function it hands to scipy.optimize.minimize.
 #include "../../mallorn-astrophysics_amd/csrc/lbfgsb_box.hpp"

@@ -35,3 +35,18 @@ def extract(set_id, csr, z=None, ncol=None, nstatus=0):
         p(out, ctypes.c_double), p(st, ctypes.c_int32))
     assert rc == 0
     return out, st
+
+
+def gp1d(csr):
+    """Per-band 1-D GP templates (csrc/gp1d.hpp) on the host -> (out[n_obj, 21], status[n_obj, 4])."""
+    L = lib()
+    n_obj = len(csr["offsets"]) - 1
+    out = np.full((n_obj, 21), np.nan)
+    st = np.zeros((n_obj, 4), np.int32)
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    L.hostsim_gp1d.restype = ctypes.c_int
+    rc = L.hostsim_gp1d(ctypes.c_int64(n_obj), p(np.ascontiguousarray(csr["offsets"], np.int64), ctypes.c_int64),
+                        p(csr["t"], ctypes.c_double), p(csr["flux"], ctypes.c_double), p(csr["err"], ctypes.c_double),
+                        p(csr["band"], ctypes.c_uint8), p(out, ctypes.c_double), p(st, ctypes.c_int32))
+    assert rc == 0
+    return out, st
