@@ -42,7 +42,8 @@ enum {
     LCFE_SET_SHAPE = 5,    /* lightcurve_shape.py:177-368    65 columns */
     LCFE_SET_PHYSICS = 6,  /* physics_based.py:292-502       32 columns */
     LCFE_SET_GP2D = 7,     /* multiband_gp.py:292-385        27 columns */
-    LCFE_NUM_SETS = 8
+    LCFE_SET_GP1D = 8,     /* gaussian_process.py:173-310    21 columns (per-band scikit-learn GP) */
+    LCFE_NUM_SETS = 9
 };
 #define LCFE_MASK(id) (1 << (id))
 #define LCFE_MASK_ALL ((1 << LCFE_NUM_SETS) - 1)
@@ -73,7 +74,8 @@ const char* lcfe_last_error(void);
 int64_t lcfe_ncols(int mask);
 const char* lcfe_colname(int mask, int64_t j);
 /* int32 status words per object for a mask: Bazin 6 x (status, nfev), power-law 27 x (status, nfev),
- * GP 4 (status, n_iter, n_eval, n_points); 0 for the other sets */
+ * GP 4 (status, n_iter, n_eval, n_points), per-band GP 4 (L-BFGS-B evaluations of g, r, i, z; -100: band
+ * longer than 159 valid points); 0 for the other sets */
 int64_t lcfe_nstatus(int mask);
 
 /*

@@ -10,8 +10,8 @@ The integer ids / bit masks below are the same constants as ``include/lcfe.h``.
 BANDS = ["u", "g", "r", "i", "z", "y"]
 
 # feature-set ids (bit = 1 << id) -- keep in sync with include/lcfe.h
-SET_STAT, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D = range(8)
-SET_NAMES = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d"]
+SET_STAT, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D = range(9)
+SET_NAMES = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d", "gp1d"]
 
 _STAT17 = ["n_obs", "mean", "std", "min", "max", "median", "skew", "kurtosis", "amplitude", "mad",
            "iqr", "beyond_1std", "beyond_2std", "max_slope", "mean_snr", "time_span", "cadence_mean"]
@@ -122,11 +122,18 @@ def _gp2d():
     return cols + ["gp_gr_slope_50d", "gp_gr_slope_100d"]
 
 
+def _gp1d():
+    # gaussian_process.py:189-246 (per-band scikit-learn GP; bands g, r, i, z)
+    cols = [f"{b}_{k}" for b in "griz" for k in ("gp_length_scale", "gp_amplitude", "gp_noise", "gp_log_likelihood")]
+    return cols + ["gp_ls_ratio_gr", "gp_ls_ratio_ri", "gp_mean_length_scale", "gp_std_length_scale",
+                   "gp_mean_amplitude"]
+
+
 COLUMNS = {"stat": _stat(), "bazin": _bazin(), "powerlaw": _powerlaw(), "tde": _tde(),
-           "color": _color(), "shape": _shape(), "physics": _physics(), "gp2d": _gp2d()}
+           "color": _color(), "shape": _shape(), "physics": _physics(), "gp2d": _gp2d(), "gp1d": _gp1d()}
 NCOLS = {k: len(v) for k, v in COLUMNS.items()}
 assert NCOLS == {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65,
-                 "physics": 32, "gp2d": 27}, NCOLS
+                 "physics": 32, "gp2d": 27, "gp1d": 21}, NCOLS
 
 # integer-valued columns of the statistics frame (int64 in the reference's DataFrame)
 STAT_INT_COLUMNS = [f"{p}_n_obs" for p in BANDS + ["all"]] + ["peak_band"]

@@ -12,7 +12,7 @@
 
 namespace lcfe {
 
-enum { SET_STAT = 0, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, NUM_SETS };
+enum { SET_STAT = 0, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D, NUM_SETS };
 
 LCFE_HD int set_ncols(int set) {
     switch (set) {
@@ -24,6 +24,7 @@ LCFE_HD int set_ncols(int set) {
         case SET_SHAPE: return 65;
         case SET_PHYSICS: return 32;
         case SET_GP2D: return 27;
+        case SET_GP1D: return 21;
     }
     return 0;
 }
@@ -36,6 +37,7 @@ LCFE_HD int set_nstatus(int set) {
 #else
         case SET_GP2D: return 4;
 #endif
+        case SET_GP1D: return 4;
     }
     return 0;
 }

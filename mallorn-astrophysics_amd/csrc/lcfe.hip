@@ -18,6 +18,7 @@
 #include "../../include/lcfe.h"
 #include "feature_sets.hpp"
 #include "stat_lean.hpp"
+#include "gp1d.hpp"
 
 using namespace lcfe;
 
@@ -355,6 +356,117 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     return 0;
 }
 
+// ---- per-band 1-D GP (gp1d.hpp): one light curve per 256-thread workgroup, its bands g, r, i, z one after
+// the other; the band's rows are an index list into the CSR slice (time order: file order when the rows
+// are sorted, a rank sort otherwise); NP - 1 = most valid points of a band, ROWCAP = most rows of the object
+template <int NP, int ROWCAP>
+__global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+                                                   int col0, int32_t* status, int st_ld, int st0,
+                                                   unsigned long long* ticket) {
+    using W = BlockDev<256>;
+    __shared__ GpLds<NP, W::NWAVES> S;
+    __shared__ double Klds[gp_store_doubles(NP)];
+    __shared__ unsigned short rows[ROWCAP], rows2[ROWCAP];
+    __shared__ long long next_ticket;
+    const int count = bins.counts[kNumBins + bin];
+    const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t pos = next_ticket;
+        __syncthreads();
+        if (pos >= count) break;
+        const int64_t i = list[pos];
+        const int64_t s = B.offsets[i];
+        const int n = (int)(B.offsets[i + 1] - s);
+        const double* t = B.t + s;
+        const double* f = B.f + s;
+        const double* e = B.e + s;
+        const uint8_t* bb = B.b + s;
+        int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
+        bool fitted[4];
+        for (int j = 0; j < 4; ++j) {
+            const int band = j + 1;                                     // g, r, i, z
+            int m = 0;
+            for (int k = threadIdx.x; k < n; k += 256) {
+                if (bb[k] != band) continue;
+                int p = 0;
+                for (int q = 0; q < k; ++q) p += (bb[q] == band) ? 1 : 0;
+                rows[p] = (unsigned short)k;
+                ++m;
+            }
+            m = W::sum(m);                                              // (two barriers: rows[] is complete)
+            bool ordered = true;
+            for (int k = threadIdx.x; k + 1 < m; k += 256) ordered = ordered && (t[rows[k]] <= t[rows[k + 1]]);
+            if (!W::all(ordered)) {
+                // stable rank sort by (time, file index), as the oracle's ``band_sorted``
+                for (int k = threadIdx.x; k < m; k += 256) {
+                    const double tk = t[rows[k]];
+                    int r = 0;
+                    for (int q = 0; q < m; ++q) {
+                        const double tq = t[rows[q]];
+                        r += (tq < tk || (tq == tk && q < k)) ? 1 : 0;
+                    }
+                    rows2[r] = rows[k];
+                }
+                __syncthreads();
+                for (int k = threadIdx.x; k < m; k += 256) rows[k] = rows2[k];
+                __syncthreads();
+            }
+            fitted[j] = m >= 5;
+            gp1d_band<W, NP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[r]; tt = t[k]; ff = f[k]; ee = e[k]; },
+                             m, S,
+                             [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, NP, lds_double*>(x, nn, S, (lds_double*)Klds, fv, gv); },
+                             S.out + 4 * j, st ? st + j : nullptr);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) gp1d_cross_band(S.out, fitted);
+        __syncthreads();
+        store_row<W>(S.out, out + i * (int64_t)ld + col0, GP1D_NCOL);
+        __syncthreads();
+    }
+    nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP1D_NCOL, status, st_ld, st0, GP1D_NSTATUS);
+}
+
+template <int NP, int ROWCAP>
+int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
+                     int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP>, 256, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid > B.n_obj) grid = B.n_obj;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP>), dim3((unsigned)grid), dim3(256), 0, stream, B, bins, bin, nan_from, out, ld,
+                       col0, status, st_ld, st0, ticket);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The GP bins are reused (by rows of the whole object): bins 0..2 run with a Gram matrix as large as the
+// object; bins 3..5 (160..767 rows) with the 160-row matrix -- a band with more than 159 valid points
+// gets NaN and status -100.
+int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
+                int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
+    const int caps[6] = {63, 111, 159, kGpSmallNP - 1, kGpMidNP - 1, kGpGlobalNP - 1};
+    int last = 0;
+    while (last < 5 && caps[last] < max_len) ++last;
+    for (int ti = last; ti >= 0; --ti) {
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        unsigned long long* tk = tickets + SET_GP1D * 8 + ti;
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_gp1d_tier<64, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 1: rc = launch_gp1d_tier<112, 112>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 2: rc = launch_gp1d_tier<160, 160>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            default: rc = launch_gp1d_tier<160, 768>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+    }
+    return 0;
+}
+
 const int kTiers[] = {128, 256, 512, 1024, 2048};
 constexpr int kMaxPoints = 2048;
 
@@ -557,13 +669,14 @@ const char* lcfe_colname(int mask, int64_t j) {
     return nullptr;
 }
 
-// workspace layout: [0, 512) ticket counters (8 per set), [512, 1024) bin counts, then the
+// workspace layout: [0, 1024) ticket counters (8 per set), [1024, 2048) bin counts, then the
 // kNumLists index lists of n_obj int32 each (256-byte aligned total), then the GP scratch slabs
+constexpr size_t kWsHeader = 2048;
 static size_t list_bytes(int64_t n_obj) {
     return (((size_t)(n_obj > 0 ? n_obj : 0) * kNumLists * sizeof(int)) + 255) & ~(size_t)255;
 }
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t) {
-    size_t b = 1024 + list_bytes(n_obj);
+    size_t b = kWsHeader + list_bytes(n_obj);
     if (mask & (1 << SET_GP2D)) b += kGpSmallBytes + kGpMidBytes + kGpGlobalBytes;
     return b;
 }
@@ -595,13 +708,13 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         prof->bytes_out = 8 * n_obj * (int64_t)ld;
     }
     const size_t lists_b = list_bytes(n_obj);
-    if (!d_workspace || workspace_bytes < 1024 + lists_b)
+    if (!d_workspace || workspace_bytes < kWsHeader + lists_b)
         return fail_msg("lcfe_extract_device: workspace smaller than lcfe_workspace_bytes(mask, n_obj, n_points)");
     unsigned long long* tickets = (unsigned long long*)d_workspace;
-    int* counts = (int*)((char*)d_workspace + 512);
-    int* lists = (int*)((char*)d_workspace + 1024);
-    double* gp_scratch = (workspace_bytes > 1024 + lists_b) ? (double*)((char*)d_workspace + 1024 + lists_b) : nullptr;
-    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - 1024 - lists_b : 0;
+    int* counts = (int*)((char*)d_workspace + 1024);
+    int* lists = (int*)((char*)d_workspace + kWsHeader);
+    double* gp_scratch = (workspace_bytes > kWsHeader + lists_b) ? (double*)((char*)d_workspace + kWsHeader + lists_b) : nullptr;
+    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - kWsHeader - lists_b : 0;
     const Bins bins{lists, counts, n_obj};
     // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
     // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
@@ -618,7 +731,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         switch (s) {
             case SET_BAZIN: return side[0];
             case SET_POWERLAW: return side[1];
-            case SET_TDE: case SET_COLOR: case SET_SHAPE: case SET_PHYSICS: return side[2];
+            case SET_TDE: case SET_COLOR: case SET_SHAPE: case SET_PHYSICS: case SET_GP1D: return side[2];
             default: return stream;
         }
     };
@@ -643,7 +756,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if (ne == 0) {
             // shared prologue (timed with the first set): zero tickets and counts, bin the objects
             if (prof) HIP_TRY(hipEventRecord(ev0[s], stream));
-            HIP_TRY(hipMemsetAsync(d_workspace, 0, 1024, stream));
+            HIP_TRY(hipMemsetAsync(d_workspace, 0, kWsHeader, stream));
             hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((n_obj + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0,
                                stream, d_offsets, n_obj, lists, counts);
             HIP_TRY(hipGetLastError());
@@ -667,6 +780,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_GP2D:
                 if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }
                 rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, fork ? side[2] : q, dev, gp_scratch,

@@ -108,7 +108,7 @@ extern "C" int hostsim_gp1d(int64_t n_obj, const int64_t* offsets, const double*
             const int b = j + 1;                                   // g, r, i, z
             const int bs = obj->boff[b], m = obj->boff[b + 1] - bs;
             fitted[j] = m >= 5;
-            gp1d_band<W, NP>(obj->bt + bs, obj->bf + bs, obj->be + bs, m, *ws,
+            gp1d_band<W, NP>([&](int r, double& tt, double& ff, double& ee) { tt = obj->bt[bs + r]; ff = obj->bf[bs + r]; ee = obj->be[bs + r]; }, m, *ws,
                              [&](const double* x, int nn, double& f, double* g) { gp1d_eval<W, NP, double*>(x, nn, *ws, K.data(), f, g); },
                              o + 4 * j, status ? status + i * GP1D_NSTATUS + j : nullptr);
         }

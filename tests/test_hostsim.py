@@ -50,3 +50,18 @@ def test_hostsim_gp2d_vs_oracle(golden_inputs):
     got[rows] = o
     mask = np.zeros(len(ref), bool); mask[rows] = True
     check_fit_parity(got[mask], "gp2d", COLUMNS["gp2d"], ref=ref[mask], probes=[p[mask] for p in probes])
+
+
+def test_gp1d_templates_match_reference_golden(golden_inputs):
+    """csrc/gp1d.hpp + lbfgsb_box.hpp on the host against the real reference module's outputs."""
+    import os
+    from conftest import ROOT
+    from synth_subset import take
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_gp1d.npz"))
+    rows = slice(0, 24)
+    got, st = hostsim_lib.gp1d(take(golden_inputs, g["pick"][rows]))
+    ref = g["out"][rows]
+    assert (np.isnan(got) == np.isnan(ref)).all()
+    both = ~np.isnan(ref)
+    rel = np.abs(got - ref)[both] / np.maximum(np.abs(ref[both]), 1e-8)
+    assert (rel <= 1e-4).mean() >= 0.97 and rel.max() <= 0.02, ((rel <= 1e-4).mean(), rel.max())
