@@ -14,8 +14,8 @@ of them in one go, every frame computed on the MI355X:
     bazin_features_cache.pkl    bazin_fitting.extract_bazin_features     (cache_bazin_features.py:39-45)
     powerlaw_features.pkl       decline-model R^2, train frame only      (visualize_and_powerlaw.py:373-375)
 
-The per-band sklearn GP cache (``gp_features_cache.pkl``) is not produced: it is not part of the
-v34a frame ("next" rows).
+    gp_features_cache.pkl       gaussian_process.extract_gp_features (per-band scikit-learn GP,
+                                precompute_features.py:58-76) -- the cache the reference script itself writes
 """
 import pickle
 import sys
@@ -31,6 +31,7 @@ from mallorn_astrophysics_amd.features.lightcurve_shape import extract_shape_fea
 from mallorn_astrophysics_amd.features.physics_based import extract_physics_features  # noqa: E402
 from mallorn_astrophysics_amd.features.tde_physics import extract_tde_physics_features  # noqa: E402
 from mallorn_astrophysics_amd.features.multiband_gp import extract_multiband_gp_features  # noqa: E402
+from mallorn_astrophysics_amd.features.gaussian_process import extract_gp_features  # noqa: E402
 from mallorn_astrophysics_amd.features.bazin_fitting import extract_bazin_features  # noqa: E402
 from mallorn_astrophysics_amd.features.powerlaw import extract_powerlaw_features  # noqa: E402
 
@@ -90,6 +91,10 @@ cached('tde_physics_cache.pkl', lambda: (extract_tde_physics_features(train_lc, 
 print("\n5. Computing multi-band GP features...", flush=True)
 cached('multiband_gp_cache.pkl', lambda: (extract_multiband_gp_features(train_lc, train_meta, train_ids),
                                           extract_multiband_gp_features(test_lc, test_meta, test_ids)))
+
+print("\n5b. Computing per-band GP length-scale features...", flush=True)
+cached('gp_features_cache.pkl', lambda: (extract_gp_features(train_lc, train_meta, train_ids, verbose=False),
+                                         extract_gp_features(test_lc, test_meta, test_ids, verbose=False)))
 
 print("\n6. Computing Bazin features...", flush=True)
 cached('bazin_features_cache.pkl', lambda: (extract_bazin_features(train_lc, train_ids),

@@ -332,7 +332,7 @@ def test_entry_point_scripts_write_the_caches(tmp_path):
     assert v4["train_features"].shape == (24, 1 + 123 + 4 + 83 + 65 + 32)
     assert len(v4["test_features"]) == 30
     for name, ncol in (("tde_physics_cache.pkl", 25), ("multiband_gp_cache.pkl", 27), ("bazin_features_cache.pkl", 52),
-                       ("enhanced_colors_cache.pkl", 83)):
+                       ("enhanced_colors_cache.pkl", 83), ("gp_features_cache.pkl", 21)):
         c = pickle.load(open(proc / name, "rb"))
         assert set(c) == {"train", "test"} and c["train"].shape == (24, ncol + 1), name
     pw = pickle.load(open(proc / "powerlaw_features.pkl", "rb"))
@@ -340,7 +340,7 @@ def test_entry_point_scripts_write_the_caches(tmp_path):
     # second run: every cache is skipped
     r = subprocess.run([_sys.executable, os.path.join(ROOT, "scripts", "precompute_features.py")], env=env,
                        capture_output=True, text=True)
-    assert r.stdout.count("already cached") == 6
+    assert r.stdout.count("already cached") == 7
 
 
 def test_full_size_properties():
