@@ -356,14 +356,15 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     return 0;
 }
 
-// ---- per-band 1-D GP (gp1d.hpp): one light curve per 256-thread workgroup, its bands g, r, i, z one after
+constexpr int kGp1dThreads = 256;       // measured: 64 threads 10.1 s, 128: 7.2 s, 256: 6.8 s per 125 k objects
+// ---- per-band 1-D GP (gp1d.hpp): one light curve per workgroup of kGp1dThreads threads, its bands g, r, i, z one after
 // the other; the band's rows are an index list into the CSR slice (time order: file order when the rows
 // are sorted, a rank sort otherwise); NP - 1 = most valid points of a band, ROWCAP = most rows of the object
-template <int NP, int ROWCAP>
-__global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+template <int NP, int ROWCAP, int T>
+__global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                    int col0, int32_t* status, int st_ld, int st0,
                                                    unsigned long long* ticket) {
-    using W = BlockDev<256>;
+    using W = BlockDev<T>;
     __shared__ GpLds<NP, W::NWAVES> S;
     __shared__ double Klds[gp_store_doubles(NP)];
     __shared__ unsigned short rows[ROWCAP], rows2[ROWCAP];
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int b
         for (int j = 0; j < 4; ++j) {
             const int band = j + 1;                                     // g, r, i, z
             int m = 0;
-            for (int k = threadIdx.x; k < n; k += 256) {
+            for (int k = threadIdx.x; k < n; k += T) {
                 if (bb[k] != band) continue;
                 int p = 0;
                 for (int q = 0; q < k; ++q) p += (bb[q] == band) ? 1 : 0;
@@ -397,10 +398,10 @@ __global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int b
             }
             m = W::sum(m);                                              // (two barriers: rows[] is complete)
             bool ordered = true;
-            for (int k = threadIdx.x; k + 1 < m; k += 256) ordered = ordered && (t[rows[k]] <= t[rows[k + 1]]);
+            for (int k = threadIdx.x; k + 1 < m; k += T) ordered = ordered && (t[rows[k]] <= t[rows[k + 1]]);
             if (!W::all(ordered)) {
                 // stable rank sort by (time, file index), as the oracle's ``band_sorted``
-                for (int k = threadIdx.x; k < m; k += 256) {
+                for (int k = threadIdx.x; k < m; k += T) {
                     const double tk = t[rows[k]];
                     int r = 0;
                     for (int q = 0; q < m; ++q) {
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int b
                     rows2[r] = rows[k];
                 }
                 __syncthreads();
-                for (int k = threadIdx.x; k < m; k += 256) rows[k] = rows2[k];
+                for (int k = threadIdx.x; k < m; k += T) rows[k] = rows2[k];
                 __syncthreads();
             }
             fitted[j] = m >= 5;
@@ -428,16 +429,16 @@ __global__ __launch_bounds__(256) void gp1d_kernel(BatchView B, Bins bins, int b
     nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP1D_NCOL, status, st_ld, st0, GP1D_NSTATUS);
 }
 
-template <int NP, int ROWCAP>
+template <int NP, int ROWCAP, int T>
 int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
                      int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T>, T, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP>), dim3((unsigned)grid), dim3(256), 0, stream, B, bins, bin, nan_from, out, ld,
+    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
                        col0, status, st_ld, st0, ticket);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -456,10 +457,10 @@ int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         unsigned long long* tk = tickets + SET_GP1D * 8 + ti;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp1d_tier<64, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 1: rc = launch_gp1d_tier<112, 112>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 2: rc = launch_gp1d_tier<160, 160>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            default: rc = launch_gp1d_tier<160, 768>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
