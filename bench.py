@@ -75,6 +75,12 @@ def cpu_baseline(sets, lc, budget_s=12.0):
     saved = {k: os.environ.pop(k) for k in list(os.environ)
              if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX"))}
     os.environ["HIP_VISIBLE_DEVICES"] = ""
+    # one BLAS/OpenMP thread per worker process: the variables must be in the environment the workers
+    # START with (numpy reads them at import), else `cores` processes x `cores` threads oversubscribe the host
+    thread_vars = ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")
+    saved_threads = {k: os.environ.get(k) for k in thread_vars}
+    for k in thread_vars:
+        os.environ[k] = "1"
     pool_cm = mp.get_context("spawn").Pool(cores, initializer=_cpu_init, initargs=(tmp.name,))
     os.environ.pop("HIP_VISIBLE_DEVICES", None)
     os.environ.update(saved)
@@ -83,6 +89,11 @@ def cpu_baseline(sets, lc, budget_s=12.0):
         t0 = time.perf_counter()
         pool.map(_cpu_worker, jobs)
         dt = time.perf_counter() - t0
+    for k, v in saved_threads.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     os.unlink(tmp.name)
     return {"value": sample / dt, "unit": "light curves/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} objects of the benchmark batch, sets {'+'.join(sets)}, "

@@ -37,6 +37,8 @@ def oracle_rows(name, n_w, seed_w):
     jobs = [(name, lo, min(lo + step, n_w)) for lo in range(0, n_w, step)]
     saved = {k: os.environ.pop(k) for k in list(os.environ) if k == "LD_PRELOAD" or k.startswith(("ROCP", "HSA_TOOLS"))}
     os.environ["HIP_VISIBLE_DEVICES"] = ""
+    for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):     # read by numpy at import in the workers
+        os.environ[k] = "1"
     pool = get_context("spawn").Pool(16, initializer=_init, initargs=(n_w, seed_w))
     os.environ.pop("HIP_VISIBLE_DEVICES", None)
     os.environ.update(saved)
