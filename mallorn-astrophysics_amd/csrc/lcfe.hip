@@ -360,14 +360,32 @@ constexpr int kGp1dThreads = 256;       // measured: 64 threads 10.1 s, 128: 7.2
 // ---- per-band 1-D GP (gp1d.hpp): one light curve per workgroup of kGp1dThreads threads, its bands g, r, i, z one after
 // the other; the band's rows are an index list into the CSR slice (time order: file order when the rows
 // are sorted, a rank sort otherwise); NP - 1 = most valid points of a band, ROWCAP = most rows of the object
-template <int NP, int ROWCAP, int T>
+// Bands of at most WNP - 1 valid points (the common case) are fitted by the four wavefronts of the workgroup
+// side by side, each on a WNP-row matrix of its own with wave-level fences only; otherwise the bands run one
+// after the other on the whole workgroup with the NP-row matrix.  Both layouts share one LDS buffer.
+template <int WNP>
+struct Gp1dWaveLds {
+    GpLds<WNP, 1> S;
+    double K[gp_store_doubles(WNP)];
+};
+template <int NP, int NW>
+struct Gp1dBlockLds {
+    GpLds<NP, NW> S;
+    double K[gp_store_doubles(NP)];
+};
+
+template <int NP, int ROWCAP, int T, int WNP>
 __global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                    int col0, int32_t* status, int st_ld, int st0,
                                                    unsigned long long* ticket) {
     using W = BlockDev<T>;
-    __shared__ GpLds<NP, W::NWAVES> S;
-    __shared__ double Klds[gp_store_doubles(NP)];
+    constexpr bool kWavePath = (T == 256);
+    constexpr size_t kBlockBytes = sizeof(Gp1dBlockLds<NP, W::NWAVES>), kWaveBytes = kWavePath ? 4 * sizeof(Gp1dWaveLds<WNP>) : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char raw[(kBlockBytes > kWaveBytes) ? kBlockBytes : kWaveBytes];
+    auto& LB = *reinterpret_cast<Gp1dBlockLds<NP, W::NWAVES>*>(raw);
     __shared__ unsigned short rows[ROWCAP], rows2[ROWCAP];
+    __shared__ double orow[GP1D_NCOL + 3];
+    __shared__ int boff[5], nvalid[4];
     __shared__ long long next_ticket;
     const int count = bins.counts[kNumBins + bin];
     const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
@@ -385,60 +403,96 @@ __global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin
         const double* e = B.e + s;
         const uint8_t* bb = B.b + s;
         int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
-        bool fitted[4];
-        for (int j = 0; j < 4; ++j) {
-            const int band = j + 1;                                     // g, r, i, z
-            int m = 0;
-            for (int k = threadIdx.x; k < n; k += T) {
-                if (bb[k] != band) continue;
-                int p = 0;
-                for (int q = 0; q < k; ++q) p += (bb[q] == band) ? 1 : 0;
-                rows[p] = (unsigned short)k;
-                ++m;
-            }
-            m = W::sum(m);                                              // (two barriers: rows[] is complete)
-            bool ordered = true;
-            for (int k = threadIdx.x; k + 1 < m; k += T) ordered = ordered && (t[rows[k]] <= t[rows[k + 1]]);
-            if (!W::all(ordered)) {
-                // stable rank sort by (time, file index), as the oracle's ``band_sorted``
+        // ---- rows of the bands g, r, i, z as one index list partitioned by band, each part in time order
+        int cnt[4] = {0, 0, 0, 0}, nv[4] = {0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += T) {
+            const int band = bb[k];
+            if (band < 1 || band > 4) continue;
+            ++cnt[band - 1];
+            if (!is_nan(f[k]) && !is_nan(e[k]) && e[k] > 0) ++nv[band - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cnt[j] = W::sum(cnt[j]); nv[j] = W::sum(nv[j]); }
+        if (threadIdx.x == 0) {
+            boff[0] = 0;
+            for (int j = 0; j < 4; ++j) { boff[j + 1] = boff[j] + cnt[j]; nvalid[j] = nv[j]; }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += T) {
+            const int band = bb[k];
+            if (band < 1 || band > 4) continue;
+            int p = 0;
+            for (int q = 0; q < k; ++q) p += (bb[q] == band) ? 1 : 0;
+            rows[boff[band - 1] + p] = (unsigned short)k;
+        }
+        __syncthreads();
+        bool ordered = true;
+        for (int k = threadIdx.x; k + 1 < n; k += T) ordered = ordered && (t[k] <= t[k + 1]);
+        if (!W::all(ordered)) {
+            // stable rank sort of every band part by (time, file index), as the oracle's ``band_sorted``
+            for (int j = 0; j < 4; ++j) {
+                const int b0 = boff[j], m = boff[j + 1] - b0;
                 for (int k = threadIdx.x; k < m; k += T) {
-                    const double tk = t[rows[k]];
+                    const double tk = t[rows[b0 + k]];
                     int r = 0;
                     for (int q = 0; q < m; ++q) {
-                        const double tq = t[rows[q]];
+                        const double tq = t[rows[b0 + q]];
                         r += (tq < tk || (tq == tk && q < k)) ? 1 : 0;
                     }
-                    rows2[r] = rows[k];
+                    rows2[b0 + r] = rows[b0 + k];
                 }
-                __syncthreads();
-                for (int k = threadIdx.x; k < m; k += T) rows[k] = rows2[k];
-                __syncthreads();
             }
-            fitted[j] = m >= 5;
-            gp1d_band<W, NP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[r]; tt = t[k]; ff = f[k]; ee = e[k]; },
-                             m, S,
-                             [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, NP, lds_double*>(x, nn, S, (lds_double*)Klds, fv, gv); },
-                             S.out + 4 * j, st ? st + j : nullptr);
+            __syncthreads();
+            for (int k = threadIdx.x; k < boff[4]; k += T) rows[k] = rows2[k];
             __syncthreads();
         }
-        if (threadIdx.x == 0) gp1d_cross_band(S.out, fitted);
+        bool fitted[4];
+        int most = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fitted[j] = (boff[j + 1] - boff[j]) >= 5; most = (nvalid[j] > most) ? nvalid[j] : most; }
+        bool done = false;
+        if constexpr (kWavePath) {
+            if (most + 1 <= WNP) {
+                // one band per wavefront
+                const int j = threadIdx.x >> 6;
+                auto& LW = reinterpret_cast<Gp1dWaveLds<WNP>*>(raw)[j];
+                const int b0 = boff[j], m = boff[j + 1] - b0;
+                gp1d_band<WaveOfBlock, WNP>(
+                    [&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; }, m, LW.S,
+                    [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<WaveOfBlock, WNP, lds_double*>(x, nn, LW.S, (lds_double*)LW.K, fv, gv); },
+                    orow + 4 * j, st ? st + j : nullptr);
+                done = true;
+            }
+        }
+        if (!done) {
+            for (int j = 0; j < 4; ++j) {
+                const int b0 = boff[j], m = boff[j + 1] - b0;
+                gp1d_band<W, NP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; },
+                                 m, LB.S,
+                                 [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, NP, lds_double*>(x, nn, LB.S, (lds_double*)LB.K, fv, gv); },
+                                 orow + 4 * j, st ? st + j : nullptr);
+                __syncthreads();
+            }
+        }
         __syncthreads();
-        store_row<W>(S.out, out + i * (int64_t)ld + col0, GP1D_NCOL);
+        if (threadIdx.x == 0) gp1d_cross_band(orow, fitted);
+        __syncthreads();
+        store_row<W>(orow, out + i * (int64_t)ld + col0, GP1D_NCOL);
         __syncthreads();
     }
     nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP1D_NCOL, status, st_ld, st0, GP1D_NSTATUS);
 }
 
-template <int NP, int ROWCAP, int T>
+template <int NP, int ROWCAP, int T, int WNP>
 int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
                      int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T>, T, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T, WNP>, T, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
+    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T, WNP>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
                        col0, status, st_ld, st0, ticket);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -457,10 +511,10 @@ int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         unsigned long long* tk = tickets + SET_GP1D * 8 + ti;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads, 32>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;

@@ -243,6 +243,35 @@ struct BlockDev {
 };
 #endif
 
+#if defined(__HIPCC__)
+// One wavefront of a larger workgroup working on data of its own while the other wavefronts of the
+// workgroup work on theirs (the four bands of the per-band GP): lane ids are wave-relative, every
+// "sync" is a wave-level fence, reductions are WaveDev's DPP/readlane ones.
+struct WaveOfBlock {
+    static constexpr int LANES = 64, WAVE = 64, NWAVES = 1, NGROUPS = 1;
+    static __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
+    static __device__ __forceinline__ int wlane() { return threadIdx.x & 63; }
+    static __device__ __forceinline__ int wave_id() { return 0; }
+    static __device__ __forceinline__ int group_id() { return 0; }
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    static __device__ __forceinline__ void wave_sync() { sync(); }
+    static __device__ __forceinline__ double sum(double v) { return WaveDev::sum(v); }
+    static __device__ __forceinline__ double max(double v) { return WaveDev::max(v); }
+    static __device__ __forceinline__ double min(double v) { return WaveDev::min(v); }
+    static __device__ __forceinline__ int sum(int v) { return WaveDev::sum(v); }
+    static __device__ __forceinline__ int max(int v) { return WaveDev::max(v); }
+    static __device__ __forceinline__ int min(int v) { return WaveDev::min(v); }
+    static __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+    static __device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0ull; }
+    static __device__ __forceinline__ bool all(bool p) { return __ballot(!p) == 0ull; }
+    static __device__ __forceinline__ double bcast_from_first_wave(double v) { return v; }
+};
+#endif
+
 struct WaveHost {
     static constexpr int LANES = 1;
     static constexpr int WAVE = 1;
