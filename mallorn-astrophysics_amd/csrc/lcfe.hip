@@ -450,22 +450,23 @@ __global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin
         int most = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fitted[j] = (boff[j + 1] - boff[j]) >= 5; most = (nvalid[j] > most) ? nvalid[j] : most; }
-        bool done = false;
+        // phase 1: every band that fits a WNP-row matrix, one per wavefront, side by side
         if constexpr (kWavePath) {
-            if (most + 1 <= WNP) {
-                // one band per wavefront
-                const int j = threadIdx.x >> 6;
+            const int j = threadIdx.x >> 6;
+            if (nvalid[j] + 1 <= WNP) {
                 auto& LW = reinterpret_cast<Gp1dWaveLds<WNP>*>(raw)[j];
                 const int b0 = boff[j], m = boff[j + 1] - b0;
                 gp1d_band<WaveOfBlock, WNP>(
                     [&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; }, m, LW.S,
                     [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<WaveOfBlock, WNP, lds_double*>(x, nn, LW.S, (lds_double*)LW.K, fv, gv); },
                     orow + 4 * j, st ? st + j : nullptr);
-                done = true;
             }
+            __syncthreads();
         }
-        if (!done) {
+        // phase 2: the longer bands one after the other on the whole workgroup (same LDS buffer, NP-row matrix)
+        if (!kWavePath || most + 1 > WNP) {
             for (int j = 0; j < 4; ++j) {
+                if (kWavePath && nvalid[j] + 1 <= WNP) continue;
                 const int b0 = boff[j], m = boff[j + 1] - b0;
                 gp1d_band<W, NP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; },
                                  m, LB.S,
