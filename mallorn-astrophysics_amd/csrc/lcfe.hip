@@ -374,8 +374,9 @@ struct Gp1dBlockLds {
     double K[gp_store_doubles(NP)];
 };
 
-template <int NP, int ROWCAP, int T, int WNP>
-__global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+// MW = waves per SIMD the register allocation leaves room for (= workgroups per CU at 256 threads)
+template <int NP, int ROWCAP, int T, int WNP, int MW>
+__global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                    int col0, int32_t* status, int st_ld, int st0,
                                                    unsigned long long* ticket) {
     using W = BlockDev<T>;
@@ -484,16 +485,16 @@ __global__ __launch_bounds__(T) void gp1d_kernel(BatchView B, Bins bins, int bin
     nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP1D_NCOL, status, st_ld, st0, GP1D_NSTATUS);
 }
 
-template <int NP, int ROWCAP, int T, int WNP>
+template <int NP, int ROWCAP, int T, int WNP, int MW>
 int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
                      int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T, WNP>, T, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T, WNP, MW>, T, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T, WNP>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
+    hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T, WNP, MW>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
                        col0, status, st_ld, st0, ticket);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -512,10 +513,10 @@ int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         unsigned long long* tk = tickets + SET_GP1D * 8 + ti;
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads, 32>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads, 64>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads, 32, 3>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads, 32, 2>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads, 64, 1>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads, 64, 1>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
