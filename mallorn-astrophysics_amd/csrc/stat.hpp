@@ -162,15 +162,20 @@ LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const dou
     if (std > 0) {
         double s3 = 0.0, s4 = 0.0;
         int c1 = 0, c2 = 0;
+        // z = (x - mean) / std through one reciprocal (1 ulp off the division: the moments keep 1e-15); the
+        // counts are exact without it: fl(|d| / std) > k  <=>  |d| > k std for k = 1, 2 (k std is exact, and the
+        // next double above k is k (1 + 2^-52), which |d| > k std already reaches before rounding)
+        const double inv_std = 1.0 / std, std2 = 2.0 * std;
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
-            const double zz = (x[r] - mean) / std;
+            const double d = x[r] - mean;
+            const double zz = d * inv_std;
             const double z2 = zz * zz;
             s3 += ok[r] ? z2 * zz : 0.0;
             s4 += ok[r] ? z2 * z2 : 0.0;
-            const double az = fabs(zz);
-            c1 += (ok[r] && az > 1.0) ? 1 : 0;
-            c2 += (ok[r] && az > 2.0) ? 1 : 0;
+            const double ad = fabs(d);
+            c1 += (ok[r] && ad > std) ? 1 : 0;
+            c2 += (ok[r] && ad > std2) ? 1 : 0;
         }
         s3 = W::sum(s3);
         s4 = W::sum(s4);
