@@ -83,7 +83,9 @@ LCFE_FN void stat_cross_band(double* o) {
 // accumulation order as the generic loops below, hence the same sums.
 // GATHER (the all-rows group of the lean kernel): the rows are stored band-partitioned and
 // `pos_of[i]` is the storage position of file row i, so time-consecutive neighbours are gathered.
-template <class W, int KPL, bool GATHER = false>
+// TIME_ENDS (lean kernel): the group's times are known to be ascending and free of NaN, so the time extent
+// is read off the first and last row instead of being reduced.
+template <class W, int KPL, bool GATHER = false, bool TIME_ENDS = false>
 LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const double* ge, int m, double* sorted,
                                    double* out17, StatPartial* part_out, const StatPartial* parts_in,
                                    const unsigned short* pos_of = nullptr) {
@@ -125,13 +127,16 @@ LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const dou
         bool nanf = false;
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
-            const double xr = x[r], ee = ge[ii[r]], tt = gt[ii[r]];
+            const double xr = x[r], ee = ge[ii[r]];
             s += ok[r] ? xr : 0.0;
             nanf = nanf || (ok[r] && is_nan(xr));
             mn = (ok[r] && xr < mn) ? xr : mn;
             mx = (ok[r] && xr > mx) ? xr : mx;
-            tmn = (ok[r] && tt < tmn) ? tt : tmn;
-            tmx = (ok[r] && tt > tmx) ? tt : tmx;
+            if constexpr (!TIME_ENDS) {
+                const double tt = gt[ii[r]];
+                tmn = (ok[r] && tt < tmn) ? tt : tmn;
+                tmx = (ok[r] && tt > tmx) ? tt : tmx;
+            }
             const bool use = ok[r] && ee > 0;
             const double q = fabs(xr) / ee;
             snr += use ? q : 0.0;
@@ -140,8 +145,8 @@ LCFE_FN void group_statistics_fast(const double* gt, const double* gf, const dou
         s = W::sum(s);
         mn = W::min(mn);
         mx = W::max(mx);
-        tmn = W::min(tmn);
-        tmx = W::max(tmx);
+        if constexpr (TIME_ENDS) { tmn = gt[0]; tmx = gt[m - 1]; }
+        else { tmn = W::min(tmn); tmx = W::max(tmx); }
         snr = W::sum(snr);
         nsnr = W::sum(nsnr);
         any_nan = W::any(nanf);

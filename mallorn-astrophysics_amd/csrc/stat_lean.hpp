@@ -109,9 +109,9 @@ __device__ __forceinline__ void stat_lean_object(int n, StatLeanLds<CAP>& L) {
             if (WG::lane() == 0) stat_empty_group(o, &L.part[k]);
         } else if (m > 64) {
         } else if (mb <= 32) {
-            group_statistics_fast<WG, 4>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[k], nullptr);
+            group_statistics_fast<WG, 4, false, true>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[k], nullptr);
         } else {
-            group_statistics_fast<WG, 8>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[k], nullptr);
+            group_statistics_fast<WG, 8, false, true>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[k], nullptr);
         }
     }
     if (big) {
@@ -121,11 +121,11 @@ __device__ __forceinline__ void stat_lean_object(int n, StatLeanLds<CAP>& L) {
             double* o = L.out + 17 * kb;
             if (m <= 64) continue;
             if (m <= 128 || CAP <= 128)
-                group_statistics_fast<W, 2>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
+                group_statistics_fast<W, 2, false, true>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
             else if (m <= 256 || CAP <= 256)
-                group_statistics_fast<W, (CAP > 128) ? 4 : 2>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
+                group_statistics_fast<W, (CAP > 128) ? 4 : 2, false, true>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
             else
-                group_statistics_fast<W, CAP / 64>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
+                group_statistics_fast<W, CAP / 64, false, true>(L.bt + s, L.bf + s, L.be + s, m, L.sorted + s, o, &L.part[kb], nullptr);
         }
     }
     W::sync();
