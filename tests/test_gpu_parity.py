@@ -102,6 +102,18 @@ def test_statistics_band_shapes():
     assert not bad, "\n".join(bad)
 
 
+def test_special_values_fuzz():
+    """NaN, +-inf, +-0, huge and tiny fluxes, NaN / inf / zero / negative errors, duplicated time stamps,
+    constant bands and heavy ties, injected into seeded light curves: every streaming set must still agree
+    with the oracle (tools/fuzz_special_values.py exits non-zero on any mismatch)."""
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    r = subprocess.run([_sys.executable, os.path.join(ROOT, "tools", "fuzz_special_values.py"), "240", "5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_unsorted_rows_match(golden_inputs):
     """Shuffling the rows of every object must not change the statistics (sort paths on device)."""
     rng = np.random.default_rng(11)

@@ -1,0 +1,57 @@
+"""Fuzz on the GPU box: seeded light curves with special values injected (NaN, +-inf, +-0, huge, tiny, negative
+or zero errors, duplicate and equal times) through the streaming sets against the CPU oracle.
+Usage: fuzz_special_values.py [n_objects] [seed]"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle, parity  # noqa: E402
+from mallorn_astrophysics_amd import synth  # noqa: E402
+from mallorn_astrophysics_amd.columns import COLUMNS  # noqa: E402
+from mallorn_astrophysics_amd.engine import extract_csr  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+rng = np.random.default_rng(seed)
+lc = synth.make_lightcurves(n, seed=seed)
+off = lc["offsets"]
+# (no pairs like +1e300 / -1e300: sums that cancel catastrophically depend on the summation order in numpy too)
+SPECIAL_F = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1e150, 1e-300]
+SPECIAL_E = [np.nan, np.inf, 0.0, -1.0, 1e-300, 1e300]
+for i in range(n):
+    s, e = off[i], off[i + 1]
+    kind = i % 6
+    if kind == 0:                                   # a few special fluxes
+        for k in rng.choice(np.arange(s, e), size=min(3, e - s), replace=False):
+            lc["flux"][k] = SPECIAL_F[rng.integers(len(SPECIAL_F))]
+    elif kind == 1:                                 # special errors
+        for k in rng.choice(np.arange(s, e), size=min(4, e - s), replace=False):
+            lc["err"][k] = SPECIAL_E[rng.integers(len(SPECIAL_E))]
+    elif kind == 2:                                 # duplicated time stamps (still ordered)
+        k = rng.integers(s, e - 1)
+        lc["t"][k + 1] = lc["t"][k]
+    elif kind == 3:                                 # constant flux in one band
+        m = lc["band"][s:e] == 2
+        lc["flux"][s:e][m] = 7.5
+    elif kind == 4:                                 # many equal values (ties in the order statistics)
+        lc["flux"][s:e] = np.round(lc["flux"][s:e])
+    # kind 5: untouched
+TOL = {"stat": dict(rtol=1e-9, atol=1e-12), "tde": dict(rtol=1e-8, atol=1e-8), "color": dict(rtol=1e-9, atol=1e-10),
+       "shape": dict(rtol=1e-8, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10)}
+INT = {"stat": [c for c in COLUMNS["stat"] if c.endswith("_n_obs") or c == "peak_band"]}
+warnings.simplefilter("ignore")
+np.seterr(all="ignore")
+total = 0
+for name in TOL:
+    got = extract_csr(name, lc, z=lc["z"])
+    ref = oracle.extract(name, lc, lc["z"])
+    bad = parity.compare(got, ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
+    total += len(bad)
+    print(name, n, "objects:", len(bad), "mismatches", flush=True)
+    for b in bad[:10]:
+        print("   ", b)
+sys.exit(1 if total else 0)
