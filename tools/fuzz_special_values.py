@@ -16,30 +16,37 @@ from mallorn_astrophysics_amd.engine import extract_csr  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 9
-rng = np.random.default_rng(seed)
-lc = synth.make_lightcurves(n, seed=seed)
-off = lc["offsets"]
 # (no pairs like +1e300 / -1e300: sums that cancel catastrophically depend on the summation order in numpy too)
 SPECIAL_F = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1e150, 1e-300]
 SPECIAL_E = [np.nan, np.inf, 0.0, -1.0, 1e-300, 1e300]
-for i in range(n):
-    s, e = off[i], off[i + 1]
-    kind = i % 6
-    if kind == 0:                                   # a few special fluxes
-        for k in rng.choice(np.arange(s, e), size=min(3, e - s), replace=False):
-            lc["flux"][k] = SPECIAL_F[rng.integers(len(SPECIAL_F))]
-    elif kind == 1:                                 # special errors
-        for k in rng.choice(np.arange(s, e), size=min(4, e - s), replace=False):
-            lc["err"][k] = SPECIAL_E[rng.integers(len(SPECIAL_E))]
-    elif kind == 2:                                 # duplicated time stamps (still ordered)
-        k = rng.integers(s, e - 1)
-        lc["t"][k + 1] = lc["t"][k]
-    elif kind == 3:                                 # constant flux in one band
-        m = lc["band"][s:e] == 2
-        lc["flux"][s:e][m] = 7.5
-    elif kind == 4:                                 # many equal values (ties in the order statistics)
-        lc["flux"][s:e] = np.round(lc["flux"][s:e])
-    # kind 5: untouched
+
+
+def inject(seed_, special_f, special_e):
+    rng = np.random.default_rng(seed_)
+    lc_ = synth.make_lightcurves(n, seed=seed_)
+    off = lc_["offsets"]
+    for i in range(n):
+        s, e = off[i], off[i + 1]
+        kind = i % 6
+        if kind == 0:                                   # a few special fluxes
+            for k in rng.choice(np.arange(s, e), size=min(3, e - s), replace=False):
+                lc_["flux"][k] = special_f[rng.integers(len(special_f))]
+        elif kind == 1:                                 # special errors
+            for k in rng.choice(np.arange(s, e), size=min(4, e - s), replace=False):
+                lc_["err"][k] = special_e[rng.integers(len(special_e))]
+        elif kind == 2:                                 # duplicated time stamps (still ordered)
+            k = rng.integers(s, e - 1)
+            lc_["t"][k + 1] = lc_["t"][k]
+        elif kind == 3:                                 # constant flux in one band
+            m = lc_["band"][s:e] == 2
+            lc_["flux"][s:e][m] = 7.5
+        elif kind == 4:                                 # many equal values (ties in the order statistics)
+            lc_["flux"][s:e] = np.round(lc_["flux"][s:e])
+        # kind 5: untouched
+    return lc_
+
+
+lc = inject(seed, SPECIAL_F, SPECIAL_E)
 TOL = {"stat": dict(rtol=1e-9, atol=1e-12), "tde": dict(rtol=1e-8, atol=1e-8), "color": dict(rtol=1e-9, atol=1e-10),
        "shape": dict(rtol=1e-8, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10)}
 INT = {"stat": [c for c in COLUMNS["stat"] if c.endswith("_n_obs") or c == "peak_band"]}
@@ -54,4 +61,23 @@ for name in TOL:
     print(name, n, "objects:", len(bad), "mismatches", flush=True)
     for b in bad[:10]:
         print("   ", b)
+# the bounded fits and the GPs: the NaN pattern must agree (the values are covered by the probe-based rules of
+# tests/); a fit that sits on the chaotic edge may flip, hence the 1 % allowance
+# Non-finite or absurd (1e150) fluxes / errors are left out here: what the reference's libraries do with them
+# (scipy's check_finite, scikit-learn's check_array, overflowing Gram matrices) is an accident of their code
+# paths, the device kernels do not chase it (the NaN patterns of the GPs differ in 2-3 % of such entries).
+if len(sys.argv) > 3 and sys.argv[3] == "fits":
+    from synth_subset import take
+    lc = inject(seed, [np.nan, 0.0, -0.0, 1e-300], [np.nan, 0.0, -1.0, 1e-300])
+    for name, m in (("bazin", n), ("powerlaw", n), ("gp2d", n), ("gp1d", min(n, 90))):
+        sub = take(lc, np.arange(m))
+        got = extract_csr(name, sub, z=sub["z"])
+        ref = oracle.extract(name, sub, sub["z"])
+        mism = int((np.isnan(got) != np.isnan(ref)).sum())
+        both = ~np.isnan(got) & ~np.isnan(ref)
+        rel = np.abs(got - ref)[both] / np.maximum(np.abs(ref[both]), 1e-8)
+        print(f"{name} {m} objects: {mism} NaN-mask mismatches of {got.size}; {100 * (rel <= 1e-4).mean():.1f}% of the values within 1e-4",
+              flush=True)
+        if mism > 0.01 * got.size:
+            total += mism
 sys.exit(1 if total else 0)
