@@ -37,23 +37,28 @@ template <class P> struct gp_is_lds_ptr { static constexpr bool value = false; }
 template <> struct gp_is_lds_ptr<lds_double*> { static constexpr bool value = true; };
 #endif
 
-// pivot-block width of the sweep: 8 for the LDS tiers and the 768-point fallback, 16 for the
-// 512-point global-scratch tier (half as many block steps, each with four MFMAs per tile)
-template <int NP> struct gp_block { static constexpr int B = (NP == 512 || NP == 240) ? 16 : 8; };
+// The sweep pivots one diagonal TILE (16 indices) per step.
+constexpr int GP_B = 16;
+// pivot-block width kept for code that sizes scratch by it
+template <int NP> struct gp_block { static constexpr int B = GP_B; };
+// row length of the pivot-column panel: NP rounded so that two consecutive k-slices of an MFMA operand read
+// (rows 4kc+lr, lr = 0, 1) fall into different halves of the 64 LDS banks
+LCFE_HD constexpr int gp_panel_ld(int np) { return ((np % 32) == 16) ? np : np + 16; }
 
-// Working memory of one object; NP = capacity in points.  The packed matrix itself (`K`, NP(NP+1)/2
-// doubles) lives in LDS for the small tiers and in a per-workgroup slab of global scratch otherwise.
+// Working memory of one object; NP = capacity in rows (valid points + the augmented residual row).  The
+// tile-packed matrix itself lives in LDS for the small tiers and in a per-workgroup slab of global scratch
+// otherwise.
 template <int NP, int NW = 4>
 struct GpLds {
     double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
     double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
-    double V[gp_block<NP>::B][NP];            // pivot-block columns A(:, P)
-    double P[(NW <= 4) ? NW : 1][gp_block<NP>::B][gp_block<NP>::B];  // per-wavefront copy (one shared copy for > 4 waves) of the pivot block -> minus its inverse
-    double Wm[gp_block<NP>::B][NP];           // A(:, P) * A(P,P)^-1
-    double lb_s[10][4], lb_y[10][4], lb_rho[10];   // L-BFGS memory (block-uniform, kept out of registers)
+    double V[GP_B][gp_panel_ld(NP)];          // pivot-tile columns A(:, P) (rows p >= bs of a partial block are zero)
+    double P[GP_B][GP_B];                     // inverse of the (identity-padded) pivot block
+    LbState<4, 10> lb;                        // L-BFGS-B state machine: advanced by thread 0 between two barriers
+    int lb_why;
     double slot[2];
     double out[GP_NCOL + 1];
-    int pivot_bad;                            // shared-copy mode: wave 0 reports a non-positive pivot
+    int pivot_bad;                            // wave 0 reports a non-positive pivot
 #ifdef LCFE_GP_PROF
     unsigned long long prof[12];
 #endif
@@ -75,266 +80,302 @@ LCFE_FN double gp_wavelength(int band) {
 
 #if defined(__HIPCC__)
 typedef double gp_v4f64 __attribute__((ext_vector_type(4)));
-#endif
 
-// Rank-8 update of all tiles for one pivot block.  On the GPU each wavefront takes whole tiles and
-// does the 16 x 16 x 8 product with two v_mfma_f64_16x16x4_f64 (operand layout measured on gfx950,
-// tools/mfma_f64_probe.hip: A lane l = (row l%16, k l/16), B lane l = (k l/16, col l%16), D lane l,
-// register v = (row l/16 + 4v, col l%16)); the host simulation uses plain loops.
-template <class W, int NP, class KP>
-LCFE_FN void gp_tile_update(KP A, int n, GpLds<NP, W::NWAVES>& S, int k0, int bs) {   // n = rows incl. the augmented one
-    constexpr int B = gp_block<NP>::B;
-    constexpr int KC = B / 4;                   // 16x16x4 MFMAs per tile
-    (void)KC;
-    const int nt = (n + 15) >> 4;
-#if defined(__HIPCC__)
-    if constexpr (W::WAVE == 64) {
-        const int l = W::wlane();
-        const int lr = l >> 4, lc = l & 15;
-        const int ntile = nt * (nt + 1) / 2;
-        constexpr int UNR = 4;                 // tiles in flight per wavefront (independent register sets)
-        for (int t0 = W::wave_id() * UNR; t0 < ntile; t0 += W::NWAVES * UNR) {
-            int ti[UNR], tj[UNR];
-            bool on[UNR];
-            gp_v4f64 c[UNR];
-            double av[UNR][KC], bv[UNR][KC];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int t = t0 + u;
-                on[u] = t < ntile;
-                const int tt = on[u] ? t : 0;
-                int r = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);      // row of the linear tile index
-                while (r * (r + 1) / 2 > tt) --r;
-                while ((r + 1) * (r + 2) / 2 <= tt) ++r;
-                ti[u] = r;
-                tj[u] = tt - r * (r + 1) / 2;
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                KP base = A + tile_base(ti[u], tj[u]);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) c[u][v] = base[((lr + 4 * v) << 4) + lc];
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int ri = (ti[u] << 4) + lc, cj = (tj[u] << 4) + lc;   // operand row / column of this lane
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc) { av[u][kc] = -S.Wm[4 * kc + lr][ri]; bv[u][kc] = S.V[4 * kc + lr][cj]; }
-            }
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][kc], bv[u][kc], c[u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (!on[u]) continue;
-                KP base = A + tile_base(ti[u], tj[u]);
-                const int col = (tj[u] << 4) + lc;
-                const bool col_in = (col >= k0 && col < k0 + bs);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int row = (ti[u] << 4) + lr + 4 * v;
-                    const bool row_in = (row >= k0 && row < k0 + bs);
-                    if (!col_in && !row_in) base[((lr + 4 * v) << 4) + lc] = c[u][v];
-                }
-            }
-        }
-        return;
-    }
-#endif
-    (void)nt;
-    for (int i = W::lane(); i < n; i += W::LANES) {
-        if (i >= k0 && i < k0 + bs) continue;
-        for (int j = 0; j <= i; ++j) {
-            if (j >= k0 && j < k0 + bs) continue;
-            double acc = 0;
-            for (int p = 0; p < gp_block<NP>::B; ++p) acc = fma(S.Wm[p][i], S.V[p][j], acc);
-            A[tri_index(i, j)] -= acc;
-        }
-    }
+// 1 / d: hardware reciprocal + two Newton steps (within an ulp of the division)
+__device__ __forceinline__ double gp_recip(double d) {
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = fma(fma(-d, inv, 1.0), inv, inv);
+    return fma(fma(-d, inv, 1.0), inv, inv);
 }
 
-// Pw <- -(identity-padded pivot block)^-1 by B single-index sweeps; returns true on a non-positive
-// pivot and adds log(pivots) to ld.  On the GPU the 8 x 8 block lives in the registers of one
-// wavefront (lane e holds element (e/8, e%8)) and the pivot row / column are fetched with lane
-// shuffles -- no LDS round trip per pivot; the host simulation goes through the Pw array.
-template <class W, int NP>
-LCFE_FN bool gp_pivot_inverse(GpLds<NP, W::NWAVES>& S, double (*Pw)[gp_block<NP>::B], int k0, int bs, double& ld) {
-    constexpr int B = gp_block<NP>::B;
-    bool bad = false;
-    double prod = 1.0;
-#if defined(__HIPCC__)
-    if constexpr (W::WAVE == 64 && B == 8) {
-        const int e = W::wlane();
-        const int a = e >> 3, b = e & 7;
-        double p = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+// One Gauss-Jordan pivot of the 16 x 16 block held by ONE wavefront, four elements per lane:
+// lane l = 4 a + c keeps P(a, 4c .. 4c+3).  The pivot column entry (a, Q) comes from the lane's own quad
+// (DPP quad broadcast), the pivot row entries (Q, 4c+r) from lane 4Q + c (LDS crossbar), the pivot from
+// a v_readlane: ~40 instructions per pivot, against ~130 for a column-per-lane layout.
+template <int Q>
+__device__ __forceinline__ void gp_inv16_pivot(double (&p)[4], int a, int c, bool& bad, double& prod) {
+    constexpr int QC = Q >> 2, QR = Q & 3;
+    const double d = WaveDev::rdlane(p[QR], 4 * Q + QC);
+    if (!(d > 0.0)) bad = true;
+    prod *= d;
+    const double inv = gp_recip(d);
+    const double paq = WaveDev::dpp<QC * 0x55>(p[QR]);            // quad_perm(QC, QC, QC, QC): (a, Q)
+    double t[4];
 #pragma unroll
-        for (int q = 0; q < B; ++q) {
-            const double d = __shfl(p, q * 9, 64);                 // pivot (q, q): uniform
-            const double paq = __shfl(p, (e & ~7) | q, 64);        // (a, q)
-            const double pqb = __shfl(p, (q << 3) | b, 64);        // (q, b)
-            if (!(d > 0.0)) bad = true;
-            prod *= d;
-            const double inv = 1.0 / d;
-            double v = p - paq * pqb * inv;
-            if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
-            if (a == q && b == q) v = -inv;
-            p = v;
-        }
-        ld += log(prod);
-        Pw[a][b] = p;
-        W::wave_sync();
-        return bad;
-    }
-#endif
-    for (int e = W::wlane(); e < B * B; e += W::WAVE) {
-        const int a = e / B, b = e % B;
-        Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
-    }
-    W::wave_sync();
-    for (int q = 0; q < B; ++q) {
-        const double d = Pw[q][q];
-        if (!(d > 0.0)) bad = true;
-        prod *= d;
-        if ((q & 7) == 7) { ld += log(prod); prod = 1.0; }          // one log per 8 pivots (no overflow)
-        const double inv = 1.0 / d;
-        constexpr int NV = (B * B + W::WAVE - 1) / W::WAVE;
-        double nv[NV];
+    for (int r = 0; r < 4; ++r) t[r] = __shfl(p[r], 4 * Q + c, 64) * inv;    // (Q, 4c+r) / d
+    const bool row_q = (a == Q), col_q = (c == QC);
 #pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            const int e = W::wlane() + c * W::WAVE;
-            const int a = e / B, b = e % B;
-            const double paq = Pw[a][q], pqb = Pw[q][b], pab = Pw[a][b];
-            double v = pab - paq * pqb * inv;
-            if (a == q || b == q) v = ((a == q) ? pqb : paq) * inv;
-            if (a == q && b == q) v = -inv;
-            nv[c] = v;
-        }
-        W::wave_sync();
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            const int e = W::wlane() + c * W::WAVE;
-            Pw[e / B][e % B] = nv[c];
-        }
-        W::wave_sync();
-    }
-    return bad;
-}
-
-// Wm = V^T * (-Pw): 16 rows of the matrix per MFMA pair on the GPU (B operand = the 8 x 8 block
-// padded to 16 columns), one row per lane otherwise.
-template <class W, int NP>
-LCFE_FN void gp_row_weights(GpLds<NP, W::NWAVES>& S, const double (*Pw)[gp_block<NP>::B], int n) {
-    constexpr int B = gp_block<NP>::B;
-#if defined(__HIPCC__)
-    if constexpr (W::WAVE == 64) {
-        const int l = W::wlane();
-        const int lr = l >> 4, lc = l & 15;
-        // B operand: (k = 4 kc + lr, col = lc): -Pw[k][col] for col < B, zero padding beyond
-        constexpr int KC = B / 4;
-        double bq[KC];
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) bq[kc] = (lc < B) ? -Pw[4 * kc + lr][lc] : 0.0;
-        const int nt = (n + 15) >> 4;
-        for (int t = W::wave_id(); t < nt; t += W::NWAVES) {
-            const int ri = (t << 4) + lc;
-            gp_v4f64 c = {0, 0, 0, 0};
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)                                   // A operand: (row = lc, k = 4 kc + lr)
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(S.V[4 * kc + lr][ri], bq[kc], c, 0, 0, 0);
-            // D lane (row = lr + 4v, col = lc): Wm[col][row]
-            if (lc < B) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) S.Wm[lc][(t << 4) + lr + 4 * v] = c[v];
-            }
-        }
-        return;
-    }
-#endif
-    for (int i = W::lane(); i < n; i += W::LANES) {
-        double vq[B];
-#pragma unroll
-        for (int q = 0; q < B; ++q) vq[q] = S.V[q][i];
-#pragma unroll
-        for (int p = 0; p < B; ++p) {
-            double sacc = 0;
-#pragma unroll
-            for (int q = 0; q < B; ++q) sacc = fma(-vq[q], Pw[q][p], sacc);
-            S.Wm[p][i] = sacc;
-        }
+    for (int r = 0; r < 4; ++r) {
+        double v = fma(-paq, t[r], p[r]);
+        v = row_q ? t[r] : v;
+        if (r == QR) v = col_q ? (row_q ? -inv : paq * inv) : v;
+        p[r] = v;
     }
 }
+template <int Q>
+__device__ __forceinline__ void gp_inv16_pivots(double (&p)[4], int a, int c, bool& bad, double& prod, double& ld) {
+    if constexpr (Q < 16) {
+        gp_inv16_pivot<Q>(p, a, c, bad, prod);
+        if constexpr ((Q & 7) == 7) {
+            // keep the running product in range: split off its exponent (the logarithm is taken once per sweep)
+            const int e = __builtin_amdgcn_frexp_exp(prod);
+            prod = __builtin_amdgcn_frexp_mant(prod);
+            ld += (double)e;
+        }
+        gp_inv16_pivots<Q + 1>(p, a, c, bad, prod, ld);
+    }
+}
+#endif
 
-// In-place inverse of the packed symmetric positive-definite matrix A (lower triangle, row-major)
-// by a BLOCKED SYMMETRIC SWEEP: for each pivot block P of B consecutive indices
+// rank of tile row i in the snake that deals the rows (longest first) to the NW wavefronts
+LCFE_FN int gp_row_owner(int i, int nt, int nw) {
+    const int k = nt - 1 - i, blk = k / nw, pos = k - blk * nw;
+    return (blk & 1) ? nw - 1 - pos : pos;
+}
+
+// In-place inverse of the tile-packed symmetric positive-definite matrix A by a BLOCKED SYMMETRIC SWEEP: for
+// each pivot block P (one diagonal tile, 16 consecutive indices; the last block may be partial)
 //     A_PP <- -A_PP^-1 ,  A_RP <- A_RP A_PP^-1 ,  A_RR <- A_RR - A_RP A_PP^-1 A_PR     (R = all other indices)
 // After all blocks A = -K^-1.  The pivots met while inverting the diagonal blocks are exactly the
 // Cholesky pivots L_jj^2, so log|K| = sum log(pivot) and "pivot <= 0" is LAPACK dpotrf's failure
-// (george: log-likelihood = -inf).  n/B block steps with two workgroup barriers each; a step is a
-// fully parallel rank-B update of the whole triangle -- this replaces the n sequential columns of
-// a textbook Cholesky + triangular inverse.
+// (george: log-likelihood = -inf).
 // The matrix carries one extra, never pivoted row n (the residual r = y - mu): the sweep turns it
 // into alpha = K^-1 r and its diagonal into -r'K^-1 r (regression use of the sweep operator), so
 // no solve or matrix-vector product is needed afterwards.
+//
+// GPU schedule.  Every wavefront OWNS whole tile rows (dealt longest-first in a snake, so the loads are even)
+// and is the only writer of their tiles.  Per step: (1) the owners copy the pivot tile column into the panel
+// V (LDS), (2) wavefront 0 inverts the pivot block in registers, (3) every wavefront forms, for each of its
+// rows i, W_i = V_i D^-1 with four fp64 MFMAs -- computed as (D^-1 V_i')' so that the result lands in the
+// registers in A-operand layout and is used at once, never stored as a panel --, writes it into the pivot
+// column / row tiles, and applies C_ij -= W_i V_j' to its tiles (four v_mfma_f64_16x16x4_f64 per tile, four
+// tiles in flight).  Three workgroup barriers per step, no per-element index arithmetic.
 template <class W, int NP, class KP>
 LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logdet) {
     const int nrow = n + 1;
-    constexpr int B = gp_block<NP>::B;
-    const int lane = W::lane();
-    constexpr bool PER_WAVE = (W::NWAVES <= 4);             // else: wave 0 inverts one shared copy
-    double (*Pw)[B] = S.P[PER_WAVE ? W::wave_id() : 0];
+    const int nt = (nrow + 15) >> 4;
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64) {
+        constexpr int NW = W::NWAVES;
+        const int l = W::wlane(), lr = l >> 4, lc = l & 15, w = W::wave_id();
+        double ld = 0.0, prod = 1.0;          // wavefront 0: exponent sum and mantissa product of the pivots
+        bool bad_acc = false;
+        for (int kt = 0, k0 = 0; k0 < n; ++kt, k0 += GP_B) {
+            const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
+            GP_T0();
+            // (1) pivot tile column -> V[p][i] = A(i, k0 + p); rows p >= bs of the panel are zero.  Tiles below the
+            //     pivot are copied (transposed) by the owner of their row, the tiles of the pivot row itself by all
+            //     wavefronts in turn; two tiles per trip so that their loads overlap.
+            for (int blk = 0;; blk += 2) {
+                int ii[2];
+                double x[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int pos = ((blk + u) & 1) ? NW - 1 - w : w;
+                    ii[u] = nt - 1 - ((blk + u) * NW + pos);
+                    KP T = A + tile_base((ii[u] > kt) ? ii[u] : kt, kt);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) x[u][v] = T[((lr + 4 * v) << 4) + lc];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (ii[u] > kt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) S.V[lc][(ii[u] << 4) + lr + 4 * v] = (lc < bs) ? x[u][v] : 0.0;
+                    }
+                if (ii[1] <= kt) break;
+            }
+            for (int j0 = w; j0 < kt; j0 += 2 * NW) {
+                double x[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = (j0 + u * NW < kt) ? j0 + u * NW : j0;
+                    KP T = A + tile_base(kt, j);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) x[u][v] = T[((lr + 4 * v) << 4) + lc];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = j0 + u * NW;
+                    if (j < kt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) S.V[lr + 4 * v][(j << 4) + lc] = (lr + 4 * v < bs) ? x[u][v] : 0.0;
+                    }
+                }
+            }
+            if (w == (kt % NW)) {
+                KP T = A + tile_base(kt, kt);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int pp = lr + 4 * v;                           // V[pp][k0 + lc] = A(k0 + lc, k0 + pp), symmetric
+                    const double x = (lc >= pp) ? T[(lc << 4) + pp] : T[(pp << 4) + lc];
+                    S.V[pp][k0 + lc] = (pp < bs) ? x : 0.0;
+                }
+            }
+            if (W::lane() == 0) S.pivot_bad = 0;
+            W::sync();
+            GP_T(0);
+            // (2) wavefront 0: D^-1 of the identity-padded pivot block, Gauss-Jordan in registers
+            if (w == 0) {
+                const int a = l >> 2, c = l & 3;
+                double p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 4 * c + r;
+                    p[r] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+                }
+                bool bad = false;
+                gp_inv16_pivots<0>(p, a, c, bad, prod, ld);
+                bad_acc = bad_acc || bad;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S.P[a][4 * c + r] = -p[r];        // the sweep leaves -D^-1
+                if (bad && l == 0) S.pivot_bad = 1;
+            }
+            W::sync();
+            if (S.pivot_bad != 0) return false;
+            GP_T(1);
+            // (3) own rows: W_i, pivot column / row tiles, rank-16 update of the other tiles
+            double dA[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) dA[kc] = S.P[lc][4 * kc + lr];      // A operand: D^-1 (row lc, k = 4 kc + lr)
+            const bool partial = bs < GP_B;
+            for (int blk = 0;; ++blk) {
+                const int pos = (blk & 1) ? NW - 1 - w : w;
+                const int i = nt - 1 - (blk * NW + pos);
+                if (i < 0) break;
+                if (i == kt && !partial) {
+                    // the whole tile row is pivot rows: its off-diagonal tiles are written by the owners of
+                    // the rows j < kt (below); the diagonal tile becomes -D^-1
+                    KP T = A + tile_base(kt, kt);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = -S.P[lr + 4 * v][lc];
+                    continue;
+                }
+                // W_i' = D^-1 V_i'  ->  register v of lane l = W_i(row lc, k = 4 v + lr): the A operand of the updates
+                gp_v4f64 wt = {0, 0, 0, 0};
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    wt = __builtin_amdgcn_mfma_f64_16x16x4f64(dA[kc], S.V[4 * kc + lr][(i << 4) + lc], wt, 0, 0, 0);
+                if (i > kt) {
+                    KP T = A + tile_base(i, kt);                          // A(16 i + lc, k0 + k) <- W_i(lc, k)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (4 * v + lr < bs) T[(lc << 4) + 4 * v + lr] = wt[v];
+                } else if (i < kt) {
+                    KP T = A + tile_base(kt, i);                          // A(k0 + k, 16 i + lc) <- W_i(lc, k)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (4 * v + lr < bs) T[((4 * v + lr) << 4) + lc] = wt[v];
+                } else {
+                    // partial last block: rows lc >= bs of the pivot tile row are ordinary rows (the augmented one)
+                    KP T = A + tile_base(kt, kt);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int k = 4 * v + lr;
+                        if (k < bs) T[(lc << 4) + k] = (lc >= bs) ? wt[v] : -S.P[lc][k];
+                    }
+                }
+                const double na[4] = {-wt[0], -wt[1], -wt[2], -wt[3]};
+                constexpr int UNR = 4;                                     // tiles in flight (independent accumulators)
+                for (int j0 = 0; j0 <= i; j0 += UNR) {
+                    gp_v4f64 c[UNR];
+                    double bv[UNR][4];
+                    bool on[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int j = j0 + u;
+                        on[u] = (j <= i) && (j != kt || i == kt);
+                        const int jj = (j <= i) ? j : i;
+                        KP T = A + tile_base(i, jj);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) c[u][v] = T[((lr + 4 * v) << 4) + lc];
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) bv[u][kc] = S.V[4 * kc + lr][(jj << 4) + lc];
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[kc], bv[u][kc], c[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        if (!on[u]) continue;
+                        const int j = j0 + u;
+                        KP T = A + tile_base(i, j);
+                        if (i != kt) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[u][v];
+                        } else {
+                            // partial pivot tile row: only its non-pivot rows (and, in the diagonal tile, columns) move
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (lr + 4 * v >= bs && (j != kt || lc >= bs)) T[((lr + 4 * v) << 4) + lc] = c[u][v];
+                        }
+                    }
+                }
+            }
+            W::sync();
+            GP_T(8);
+        }
+        // log|K| = (sum of exponents) ln 2 + log(mantissa product), known to wavefront 0
+        double tot = (w == 0) ? (ld * 0.6931471805599453 + log(prod)) : 0.0;
+        (void)bad_acc;
+        logdet = W::bcast_from_first_wave(tot);
+        return true;
+    }
+#endif
+    // ---- host simulation (one lane): the same blocked sweep in plain loops
     double ld = 0.0;
-    for (int k0 = 0; k0 < n; k0 += B) {
-        const int bs = (n - k0 < B) ? n - k0 : B;
-        GP_T0();
-        // (1) V[p][i] = A(i, k0+p) for every i (symmetric access); rows p >= bs are zero padding
-        for (int idx = lane; idx < B * NP; idx += W::LANES) {
-            const int p = idx / NP, i = idx - p * NP;       // NP is a compile-time constant
-            if (i < nrow) {
+    static thread_local double Wm[GP_B][NP + 16];
+    for (int k0 = 0; k0 < n; k0 += GP_B) {
+        const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
+        for (int p = 0; p < GP_B; ++p)
+            for (int i = 0; i < nrow; ++i) {
                 const int kp = k0 + p;
                 S.V[p][i] = (p < bs) ? ((i >= kp) ? A[tri_index(i, kp)] : A[tri_index(kp, i)]) : 0.0;
             }
+        double (*Pw)[GP_B] = S.P;
+        for (int a = 0; a < GP_B; ++a)
+            for (int b = 0; b < GP_B; ++b) Pw[a][b] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+        for (int q = 0; q < GP_B; ++q) {
+            const double d = Pw[q][q];
+            if (!(d > 0.0)) return false;
+            ld += log(d);
+            const double inv = 1.0 / d;
+            double nv[GP_B][GP_B];
+            for (int a = 0; a < GP_B; ++a)
+                for (int b = 0; b < GP_B; ++b) {
+                    double v = Pw[a][b] - Pw[a][q] * (Pw[q][b] * inv);
+                    if (a == q) v = Pw[q][b] * inv;
+                    if (b == q) v = (a == q) ? -inv : Pw[a][q] * inv;
+                    nv[a][b] = v;
+                }
+            for (int a = 0; a < GP_B; ++a)
+                for (int b = 0; b < GP_B; ++b) Pw[a][b] = nv[a][b];
         }
-        if (!PER_WAVE && lane == 0) S.pivot_bad = 0;
-        W::sync();
-        GP_T(0);
-        // (2) inversion of the (identity-padded) pivot block by B single-index sweeps with only
-        //     wave-level hand-offs: every wavefront on its own copy, or wave 0 on a shared one
-        bool bad = false;
-        if (PER_WAVE || W::wave_id() == 0) {
-            bad = gp_pivot_inverse<W, NP>(S, Pw, k0, bs, ld);
-            if (!PER_WAVE && bad && W::wlane() == 0) S.pivot_bad = 1;
-        }
-        if (!PER_WAVE) {
-            W::sync();
-            bad = (S.pivot_bad != 0);
-            // log-determinant: only wave 0 accumulated it; every lane needs the same value
-            ld = W::bcast_from_first_wave(ld);
-        }
-        if (bad) return false;
-        GP_T(1);
-        // now Pw = -A_PP^-1 (padding: -1 on the diagonal, met only by zero rows of V)
-        // (3) Wm[p][i] = sum_q V[q][i] * Pinv[q][p]   (Pinv = -Pw)
-        gp_row_weights<W, NP>(S, Pw, nrow);
-        W::sync();
-        GP_T(2);
-        // (4) rank-B update of every tile: C -= Wm(rows of the tile) * V(columns of the tile)^T.
-        //     Elements in pivot rows / columns are not stored (they are rewritten in (5)).
-        gp_tile_update<W, NP, KP>(A, nrow, S, k0, bs);
-        GP_T(8);
-        // (5) new pivot rows / columns:  A_RP <- A_RP A_PP^-1 ,  A_PP <- -A_PP^-1  (disjoint from (4))
-        for (int idx = lane; idx < B * NP; idx += W::LANES) {
-            const int p = idx / NP, i = idx - p * NP;
-            if (i < nrow && p < bs) {
-                const int kp = k0 + p;
-                const bool in_blk = (i >= k0 && i < k0 + bs);
-                const double v = in_blk ? Pw[i - k0][p] : S.Wm[p][i];
-                if (i >= kp) A[tri_index(i, kp)] = v; else if (!in_blk) A[tri_index(kp, i)] = v;
+        for (int a = 0; a < GP_B; ++a)
+            for (int b = 0; b < GP_B; ++b) Pw[a][b] = -Pw[a][b];       // D^-1 (identity-padded)
+        for (int i = 0; i < nrow; ++i)
+            for (int p = 0; p < GP_B; ++p) {
+                double sacc = 0;
+                for (int q = 0; q < GP_B; ++q) sacc = fma(S.V[q][i], Pw[q][p], sacc);
+                Wm[p][i] = sacc;
+            }
+        for (int i = 0; i < nrow; ++i) {
+            const bool row_in = (i >= k0 && i < k0 + bs);
+            for (int j = 0; j <= i; ++j) {
+                const bool col_in = (j >= k0 && j < k0 + bs);
+                if (row_in && col_in) A[tri_index(i, j)] = -Pw[i - k0][j - k0];
+                else if (col_in) A[tri_index(i, j)] = Wm[j - k0][i];
+                else if (row_in) A[tri_index(i, j)] = Wm[i - k0][j];
+                else {
+                    double acc = 0;
+                    for (int p = 0; p < GP_B; ++p) acc = fma(Wm[p][i], S.V[p][j], acc);
+                    A[tri_index(i, j)] -= acc;
+                }
             }
         }
-        W::sync();
-        GP_T(3);
     }
+    (void)nt;
     logdet = ld;
     return true;
 }
@@ -358,7 +399,44 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     const int rl = lane / G, cl = lane % G;
     const double mu = p[0], c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
     GP_T0();
-    // Gram matrix, packed lower
+    // Gram matrix, tile-packed lower triangle
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64) {
+        // every wavefront fills the tiles of the rows it owns in the sweep (D-operand layout: lane l, register v
+        // = element (lr + 4v, lc) of the tile): no index arithmetic per element, conflict-free 512-byte stores
+        constexpr int NW = W::NWAVES;
+        const int l = W::wlane(), lr = l >> 4, lc = l & 15, w = W::wave_id();
+        const int nt = (n + 16) >> 4;
+        for (int blk = 0;; ++blk) {
+            const int pos = (blk & 1) ? NW - 1 - w : w;
+            const int i = nt - 1 - (blk * NW + pos);
+            if (i < 0) break;
+            double ti[4], li[4], ni[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = (i << 4) + lr + 4 * v;
+                ti[v] = S.t[r]; li[v] = S.lam[r]; ni[v] = S.e2[r] + GP_TINY;
+            }
+            for (int j = 0; j <= i; ++j) {
+                const int cj = (j << 4) + lc;
+                const double tj = S.t[cj], lj = S.lam[cj], rj = S.y[cj] - mu;
+                KP T = K + tile_base(i, j);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = (i << 4) + lr + 4 * v;
+                    const double dt = ti[v] - tj, dl = li[v] - lj;
+                    double e;
+                    double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
+                    if (r == cj) k += ni[v];
+                    // rows / columns beyond the points: the augmented residual row, zeros elsewhere
+                    if (r >= n || cj >= n) k = (r == n && cj < n) ? rj : 0.0;
+                    T[((lr + 4 * v) << 4) + lc] = k;
+                }
+            }
+        }
+    } else
+#endif
+    {
     for (int i = rl; i < n; i += RG) {
         const double ti = S.t[i], li = S.lam[i];
         for (int j = cl; j <= i; j += G) {
@@ -370,6 +448,7 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
         }
     }
     for (int i = lane; i <= n; i += W::LANES) K[tri_index(n, i)] = (i < n) ? S.y[i] - mu : 0.0;   // augmented row
+    }
     W::sync();
     GP_T(4);
     double logdet;
@@ -392,6 +471,44 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     if (!need_grad) return;
     // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta ,  Kinv_ij = -K[ij]
     double g1 = 0, g2 = 0, g3 = 0;
+#if defined(__HIPCC__)
+    if constexpr (W::WAVE == 64) {
+        constexpr int NW = W::NWAVES;
+        const int l = W::wlane(), lr = l >> 4, lc = l & 15, w = W::wave_id();
+        const int nt = (n + 15) >> 4;                    // tile rows that hold points
+        for (int blk = 0;; ++blk) {
+            const int pos = (blk & 1) ? NW - 1 - w : w;
+            const int i = nt - 1 - (blk * NW + pos);
+            if (i < 0) break;
+            double ti[4], li[4], ai[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = (i << 4) + lr + 4 * v;
+                ti[v] = S.t[r]; li[v] = S.lam[r]; ai[v] = S.alpha[r];
+            }
+            for (int j = 0; j <= i; ++j) {
+                const int cj = (j << 4) + lc;
+                const double tj = S.t[cj], lj = S.lam[cj], aj = S.alpha[cj];
+                KP T = K + tile_base(i, j);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = (i << 4) + lr + 4 * v;
+                    // lower triangle inside the points: weight 2 off the diagonal, 1 on it; everything else is
+                    // masked out (its inputs may be stale memory)
+                    const bool in = (r < n && cj <= r);
+                    const double dt = in ? ti[v] - tj : 0.0, dl = in ? li[v] - lj : 0.0;
+                    const double dt2 = dt * dt, dl2 = dl * dl;
+                    double e;
+                    const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
+                    const double a = in ? (ai[v] * aj + T[((lr + 4 * v) << 4) + lc]) * ((cj == r) ? 1.0 : 2.0) : 0.0;
+                    g1 += a * k;
+                    g2 += a * e * dt2 / m0;
+                    g3 += a * e * dl2 / m1;
+                }
+            }
+        }
+    } else
+#endif
     for (int i = rl; i < n; i += RG) {
         const double ai = S.alpha[i], ti = S.t[i], li = S.lam[i];
         for (int j = cl; j <= i; j += G) {
@@ -498,8 +615,26 @@ LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, Ev&& gp_ev, int3
     double fval = 0;
     int n_iter = 0, n_eval = 0, why = LB_ERROR;
     if (finite0) {
-        auto ev = [&](const double* x, double& f, double* g) { gp_ev(x, n, f, g, true); };
-        why = lbfgsb_minimize<4, 10>(p, fval, ev, 100, 1e7, 1e-5, 20, n_iter, n_eval, S.lb_s, S.lb_y, S.lb_rho);
+        // the optimiser's state machine lives in LDS and is advanced by ONE thread between two barriers:
+        // none of its state is live in registers while the objective (the wide code) runs
+        if (lane == 0) lb_start(S.lb, p, 100, 1e7, 1e-5, 20);
+        W::sync();
+        for (;;) {
+            double fe, ge[4];
+            gp_ev(S.lb.x, n, fe, ge, true);
+            if (lane == 0) {
+                S.lb.f = fe;
+                S.lb.g[0] = ge[0]; S.lb.g[1] = ge[1]; S.lb.g[2] = ge[2]; S.lb.g[3] = ge[3];
+                S.lb_why = lb_advance(S.lb);
+            }
+            W::sync();
+            if (S.lb_why != LB_EVAL) break;
+        }
+        why = S.lb_why;
+        n_iter = S.lb.n_iter;
+        n_eval = S.lb.n_eval;
+        fval = S.lb.f;
+        p[0] = S.lb.x[0]; p[1] = S.lb.x[1]; p[2] = S.lb.x[2]; p[3] = S.lb.x[3];
     }
     if (st && lane == 0) { st[0] = why; st[1] = n_iter; st[2] = n_eval; }
 #ifdef LCFE_GP_PROF

@@ -172,132 +172,190 @@ LCFE_FN int dcsrch(double f, double g, double& stp, double ftol, double gtol, do
     return LS_FG;
 }
 
-enum { LB_CONVERGED_PG = 1, LB_CONVERGED_F = 2, LB_MAXITER = 3, LB_ABNORMAL = 4, LB_ERROR = 5 };
+enum { LB_EVAL = 0, LB_CONVERGED_PG = 1, LB_CONVERGED_F = 2, LB_MAXITER = 3, LB_ABNORMAL = 4, LB_ERROR = 5 };
 
-// Minimise over N variables.  `eval(x, f, g)` is called by every lane with uniform arguments and
-// must return uniform results.  Returns the stop reason; x, f hold the final iterate.
-template <int N, int M, class Eval>
-LCFE_FN int lbfgsb_minimize(double x[N], double& f, Eval&& eval, int maxiter, double factr, double pgtol,
-                            int maxls, int& n_iter, int& n_eval, double (*Sm)[N], double (*Ym)[N], double* rho) {
-    // Sm, Ym, rho: circular memory of the (s, y) pairs -- M rows of caller-provided (wave-shared)
-    // storage; every lane writes the same values, so no fence is needed between lanes.
-    double g[N], d[N], t[N], r[N];
-    int col = 0, head = 0;
-    double theta = 1.0;
-    n_iter = 0;
-    n_eval = 0;
-    eval(x, f, g);
-    n_eval = 1;
-    double sbgnrm = 0;
+// Reverse-communication state of one minimisation over N variables with M correction pairs.  The
+// caller evaluates f and g at `x`, stores them here and calls lb_advance(), which either asks for
+// another evaluation (LB_EVAL, new trial point in `x`) or returns the stop reason (final iterate in
+// `x`, `f`).  On the GPU the state lives in LDS and ONE thread advances it between two workgroup
+// barriers: nothing of the optimiser is live in registers while the (wide, register-hungry)
+// objective runs, so the objective's kernel is allocated for the linear algebra alone.
+template <int N, int M>
+struct LbState {
+    double x[N], f, g[N];
+    double d[N], t[N], r[N];
+    double Sm[M][N], Ym[M][N], rho[M];      // circular memory of the (s, y) pairs
+    double theta, fold, stp, gdold;
+    double factr, pgtol;
+    Dcsrch ls;
+    int col, head, n_iter, n_eval, ifun, phase, maxiter, maxls, first;
+};
+
+template <int N, int M>
+LCFE_FN void lb_start(LbState<N, M>& S, const double* x0, int maxiter, double factr, double pgtol, int maxls) {
+    for (int i = 0; i < N; ++i) S.x[i] = x0[i];
+    S.col = 0; S.head = 0; S.theta = 1.0;
+    S.n_iter = 0; S.n_eval = 0; S.phase = 0; S.ifun = 0; S.first = 1;
+    S.maxiter = maxiter; S.maxls = maxls; S.factr = factr; S.pgtol = pgtol;
+}
+
+// One step of the state machine after an evaluation of (f, g) at S.x.  Scalar code (one thread).
+template <int N, int M>
+LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
+    double x[N], g[N], d[N];
+    double f = S.f;
 #pragma unroll
-    for (int i = 0; i < N; ++i) sbgnrm = fmax(sbgnrm, fabs(g[i]));
-    if (sbgnrm <= pgtol) return LB_CONVERGED_PG;
-    while (true) {
-        // ---- search direction d = -H g
-        if (col == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) d[i] = -g[i] / theta;
-        } else {
-            double q[N], al[M];
-#pragma unroll
-            for (int i = 0; i < N; ++i) q[i] = g[i];
-            for (int k = col - 1; k >= 0; --k) {
-                const int idx = (head + k) % M;
-                double a = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) a += Sm[idx][i] * q[i];
-                a *= rho[idx];
-                al[k] = a;
-#pragma unroll
-                for (int i = 0; i < N; ++i) q[i] -= a * Ym[idx][i];
-            }
-#pragma unroll
-            for (int i = 0; i < N; ++i) q[i] /= theta;
-            for (int k = 0; k < col; ++k) {
-                const int idx = (head + k) % M;
-                double b = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) b += Ym[idx][i] * q[i];
-                b *= rho[idx];
-#pragma unroll
-                for (int i = 0; i < N; ++i) q[i] += (al[k] - b) * Sm[idx][i];
-            }
-#pragma unroll
-            for (int i = 0; i < N; ++i) d[i] = -q[i];
-        }
-        // ---- line search (lnsrlb)
-        double dtd = 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) dtd += d[i] * d[i];
-        const double dnorm = sqrt(dtd);
-        const double stpmx = 1e10;
-        double stp = (n_iter == 0) ? fmin(1.0 / dnorm, stpmx) : 1.0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) { t[i] = x[i]; r[i] = g[i]; }
-        const double fold = f;
-        int ifun = 0, iback = 0;
-        double gd = 0, gdold = 0;
-        Dcsrch ls;
-        bool ls_fail = false, first = true;
-        while (true) {
-            gd = 0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) gd += g[i] * d[i];
-            if (ifun == 0) {
-                gdold = gd;
-                if (gd >= 0.0) { ls_fail = true; break; }      // ascent direction: info = -4
-            }
-            const int task = dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, first, ls);
-            first = false;
-            if (task == LS_ERROR) { ls_fail = true; break; }
-            if (task == LS_CONV || task == LS_WARN) break;
-            ++ifun;
-            iback = ifun - 1;
-            if (iback >= maxls) { ls_fail = true; break; }     // checked by mainlb after the return
-#pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = stp * d[i] + t[i];
-            eval(x, f, g);
-            ++n_eval;
-        }
-        if (ls_fail) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) { x[i] = t[i]; g[i] = r[i]; }
-            f = fold;
-            if (col == 0) return LB_ABNORMAL;                  // ABNORMAL_TERMINATION_IN_LNSRCH
-            col = 0; head = 0; theta = 1.0;                    // refresh the memory and restart
-            continue;
-        }
-        // ---- new iterate
-        ++n_iter;
-        sbgnrm = 0;
+    for (int i = 0; i < N; ++i) { x[i] = S.x[i]; g[i] = S.g[i]; d[i] = S.d[i]; }
+    ++S.n_eval;
+    const double stpmx = 1e10;
+    bool in_search = (S.phase != 0);
+    if (!in_search) {
+        double sbgnrm = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) sbgnrm = fmax(sbgnrm, fabs(g[i]));
-        if (sbgnrm <= pgtol) return LB_CONVERGED_PG;
-        const double ddum0 = max3(fabs(fold), fabs(f), 1.0);
-        if ((fold - f) <= LB_EPS * factr * ddum0) return LB_CONVERGED_F;
-        if (n_iter >= maxiter) return LB_MAXITER;              // scipy driver: STOP at NEW_X
-        // ---- BFGS update
-        double rr = 0, dr, ddum;
+        if (sbgnrm <= S.pgtol) return LB_CONVERGED_PG;
+    }
+    while (true) {
+        if (!in_search) {
+            // ---- search direction d = -H g
+            if (S.col == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { r[i] = g[i] - r[i]; rr += r[i] * r[i]; }
+                for (int i = 0; i < N; ++i) d[i] = -g[i] / S.theta;
+            } else {
+                double q[N], al[M];
+#pragma unroll
+                for (int i = 0; i < N; ++i) q[i] = g[i];
+                for (int k = S.col - 1; k >= 0; --k) {
+                    const int idx = (S.head + k) % M;
+                    double a = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) a += S.Sm[idx][i] * q[i];
+                    a *= S.rho[idx];
+                    al[k] = a;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) q[i] -= a * S.Ym[idx][i];
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) q[i] /= S.theta;
+                for (int k = 0; k < S.col; ++k) {
+                    const int idx = (S.head + k) % M;
+                    double b = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) b += S.Ym[idx][i] * q[i];
+                    b *= S.rho[idx];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) q[i] += (al[k] - b) * S.Sm[idx][i];
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[i] = -q[i];
+            }
+            // ---- line search (lnsrlb): first trial step
+            double dtd = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) dtd += d[i] * d[i];
+            const double dnorm = sqrt(dtd);
+            S.stp = (S.n_iter == 0) ? fmin(1.0 / dnorm, stpmx) : 1.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { S.t[i] = x[i]; S.r[i] = g[i]; S.d[i] = d[i]; }
+            S.fold = f;
+            S.ifun = 0;
+            S.first = 1;
+            in_search = true;
+        }
+        // ---- one pass of the line-search loop at the current (f, g)
+        double gd = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) gd += g[i] * d[i];
+        bool ls_fail = false, ls_done = false;
+        if (S.ifun == 0) {
+            S.gdold = gd;
+            if (gd >= 0.0) ls_fail = true;                     // ascent direction: info = -4
+        }
+        if (!ls_fail) {
+            double stp = S.stp;
+            const int task = dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, S.first != 0, S.ls);
+            S.stp = stp;
+            S.first = 0;
+            if (task == LS_ERROR) ls_fail = true;
+            else if (task == LS_CONV || task == LS_WARN) ls_done = true;
+            else {
+                ++S.ifun;
+                if (S.ifun - 1 >= S.maxls) ls_fail = true;     // checked by mainlb after the return
+                else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) S.x[i] = stp * d[i] + S.t[i];
+                    S.phase = 1;
+                    return LB_EVAL;
+                }
+            }
+        }
+        in_search = false;
+        if (ls_fail) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = S.t[i]; g[i] = S.r[i]; S.x[i] = x[i]; S.g[i] = g[i]; }
+            f = S.fold;
+            S.f = f;
+            if (S.col == 0) return LB_ABNORMAL;                // ABNORMAL_TERMINATION_IN_LNSRCH
+            S.col = 0; S.head = 0; S.theta = 1.0;              // refresh the memory and restart
+            continue;
+        }
+        (void)ls_done;
+        // ---- new iterate
+        ++S.n_iter;
+        double sbgnrm = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) sbgnrm = fmax(sbgnrm, fabs(g[i]));
+        if (sbgnrm <= S.pgtol) return LB_CONVERGED_PG;
+        const double ddum0 = max3(fabs(S.fold), fabs(f), 1.0);
+        if ((S.fold - f) <= LB_EPS * S.factr * ddum0) return LB_CONVERGED_F;
+        if (S.n_iter >= S.maxiter) return LB_MAXITER;          // scipy driver: STOP at NEW_X
+        // ---- BFGS update
+        double rr = 0, dr, ddum, r[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[i] = g[i] - S.r[i]; rr += r[i] * r[i]; }
+        const double stp = S.stp;
         if (stp == 1.0) {
-            dr = gd - gdold;
-            ddum = -gdold;
+            dr = gd - S.gdold;
+            ddum = -S.gdold;
         } else {
-            dr = (gd - gdold) * stp;
+            dr = (gd - S.gdold) * stp;
 #pragma unroll
             for (int i = 0; i < N; ++i) d[i] *= stp;
-            ddum = -gdold * stp;
+            ddum = -S.gdold * stp;
         }
         if (dr <= LB_EPS * ddum) continue;                     // skip the update
         int slot;
-        if (col < M) { slot = (head + col) % M; ++col; }
-        else { slot = head; head = (head + 1) % M; }
+        if (S.col < M) { slot = (S.head + S.col) % M; ++S.col; }
+        else { slot = S.head; S.head = (S.head + 1) % M; }
 #pragma unroll
-        for (int i = 0; i < N; ++i) { Sm[slot][i] = d[i]; Ym[slot][i] = r[i]; }
-        rho[slot] = 1.0 / dr;
-        theta = rr / dr;
+        for (int i = 0; i < N; ++i) { S.Sm[slot][i] = d[i]; S.Ym[slot][i] = r[i]; }
+        S.rho[slot] = 1.0 / dr;
+        S.theta = rr / dr;
     }
+}
+
+// Minimise over N variables with a caller-supplied state (wave/block-shared storage on the GPU).
+// `eval(x, f, g)` is called by every lane with uniform arguments and must return uniform results;
+// every lane advances the state redundantly (same values), so no fence is needed between lanes.
+// Returns the stop reason; x, f hold the final iterate.
+template <int N, int M, class Eval>
+LCFE_FN int lbfgsb_minimize(double x[N], double& f, Eval&& eval, int maxiter, double factr, double pgtol,
+                            int maxls, int& n_iter, int& n_eval, LbState<N, M>& S) {
+    lb_start(S, x, maxiter, factr, pgtol, maxls);
+    int why;
+    do {
+        double xx[N], ff, gg[N];
+        for (int i = 0; i < N; ++i) xx[i] = S.x[i];
+        eval(xx, ff, gg);
+        S.f = ff;
+        for (int i = 0; i < N; ++i) S.g[i] = gg[i];
+        why = lb_advance(S);
+    } while (why == LB_EVAL);
+    for (int i = 0; i < N; ++i) x[i] = S.x[i];
+    f = S.f;
+    n_iter = S.n_iter;
+    n_eval = S.n_eval;
+    return why;
 }
 
 }  // namespace lcfe
