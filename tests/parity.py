@@ -107,3 +107,54 @@ def compare_fits(got, ref, probes, name, cols, rtol=1e-4, floor=1e-9):
                "scipy_self_close_frac": float(close_self[attempted].mean()),
                "nan_mask_mismatches": nan_mis}
     return bad, summary
+
+
+def cost_columns(name):
+    """Index of the converged-cost column of every fit block: the reduced chi^2 of a Bazin band fit
+    (bazin_fitting.py:148-151) / the R^2 of a decline model (train_v55_powerlaw.py:186-190)."""
+    if name == "bazin":
+        return [8 * k + 5 for k in range(6)], +1          # lower is better
+    if name == "powerlaw":
+        return list(range(27)), -1                        # higher is better
+    raise KeyError(name)
+
+
+def compare_cost(got, ref, probes, name, floor=1e-12):
+    """What TRF actually converges is the COST, to ftol = 1e-8.  Returns the shares, over the fits both sides
+    carried out, of (a) costs within 1e-6 relative of the reference's and (b) costs worse than the reference's by
+    more than 1e-3 relative, for the implementation and for the reference re-run under one-ulp probes."""
+    cols, sign = cost_columns(name)
+    g, r = got[:, cols], ref[:, cols]
+    both = ~np.isnan(g) & ~np.isnan(r)
+
+    def shares(x, mask):
+        with np.errstate(all="ignore"):
+            d = (x - r) / np.maximum(np.abs(r), floor)
+        d = d[mask]
+        return float((np.abs(d) <= 1e-6).mean()), float((sign * d > 1e-3).mean())
+
+    close, worse = shares(g, both)
+    self_close, self_worse = [], []
+    for p in probes:
+        x = p[:, cols]
+        c, w = shares(x, ~np.isnan(x) & ~np.isnan(r))
+        self_close.append(c)
+        self_worse.append(w)
+    return {"n": int(both.sum()), "close_1e-6": close, "worse_1e-3": worse,
+            "self_close_1e-6": float(np.mean(self_close)), "self_worse_1e-3": float(np.mean(self_worse))}
+
+
+def bazin_nfev_table(csr, nfev_log):
+    """[n_obj, 6] table of the reference's nfev per band fit from the call-order log of
+    tests/golden/make_golden.py (one entry per band with >= 5 rows, -1 where curve_fit raised); -2 = no call."""
+    off, band = csr["offsets"], csr["band"]
+    tab = np.full((len(off) - 1, 6), -2, np.int64)
+    k = 0
+    for i in range(len(off) - 1):
+        b = band[off[i]:off[i + 1]]
+        for j in range(6):
+            if (b == j).sum() >= 5:
+                tab[i, j] = nfev_log[k]
+                k += 1
+    assert k == len(nfev_log)
+    return tab

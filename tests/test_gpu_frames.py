@@ -1,0 +1,90 @@
+"""The deliverable of the path: the v34a / v92d model matrices built from frames the
+MI355X computed, against the matrices the REFERENCE's statements built from the REFERENCE's extractor outputs
+(tests/golden/golden_frames.npz; the 27 GP2D columns of the fixture come from the oracle -- george is absent,
+parity unpinned for them).
+
+Names, order and dtypes must be identical.  Values: the columns of the streaming sets and the metadata under the
+tolerances of test_gpu_parity.TOL, identical NaN mask; the Bazin / GP2D columns under the seeded-sample rule of
+test_gpu_configs (share within 1e-4, NaN-mask mismatches <= 1 %)."""
+import numpy as np
+import pytest
+
+import frames_fixture as fx
+from mallorn_astrophysics_amd import frames, synth
+from mallorn_astrophysics_amd.columns import COLUMNS, STAT_INT_COLUMNS
+from test_gpu_parity import TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def build_caches(lc, ids):
+    from mallorn_astrophysics_amd.features.statistical import extract_statistical_features, add_metadata_features
+    from mallorn_astrophysics_amd.features.colors import extract_color_features
+    from mallorn_astrophysics_amd.features.lightcurve_shape import extract_shape_features
+    from mallorn_astrophysics_amd.features.physics_based import extract_physics_features
+    from mallorn_astrophysics_amd.features.tde_physics import extract_tde_physics_features
+    from mallorn_astrophysics_amd.features.multiband_gp import extract_multiband_gp_features
+    from mallorn_astrophysics_amd.features.bazin_fitting import extract_bazin_features
+    df, meta = synth.to_dataframe(lc, ids)
+    base = add_metadata_features(extract_statistical_features(df, ids), meta)        # train_v4_physics.py:60-80
+    for other in (extract_color_features(df, ids), extract_shape_features(df, ids), extract_physics_features(df, meta, ids)):
+        base = base.merge(other, on="object_id", how="left")
+    return (base, extract_tde_physics_features(df, ids), extract_multiband_gp_features(df, meta, ids, verbose=False),
+            extract_bazin_features(df, ids))
+
+
+def set_of(col):
+    for s in ("stat", "color", "shape", "physics", "tde", "gp2d", "bazin"):
+        if col in COLUMNS[s]:
+            return s
+    return "meta"
+
+
+def compare_matrix(X, ref, names):
+    assert X.shape == ref.shape
+    fit_close = {"bazin": [], "gp2d": []}
+    fit_nan = {"bazin": [], "gp2d": []}
+    for j, c in enumerate(names):
+        s = set_of(c)
+        a, b = X[:, j], ref[:, j]
+        if s in fit_close:
+            fit_nan[s].append(np.isnan(a) != np.isnan(b))
+            both = ~np.isnan(a) & ~np.isnan(b)
+            with np.errstate(all="ignore"):
+                fit_close[s].append((np.abs(a - b)[both] / np.maximum(np.abs(b[both]), 1e-9)) <= 1e-4)
+            continue
+        assert np.array_equal(np.isnan(a), np.isnan(b)), c
+        tol = TOL.get(s, dict(rtol=0.0, atol=0.0))
+        both = ~np.isnan(b)
+        if c in STAT_INT_COLUMNS:
+            assert np.array_equal(a[both], b[both]), c
+        else:
+            err = np.abs(a - b)[both]
+            ok = (err <= tol["atol"] + tol["rtol"] * np.abs(b[both])) | (a[both] == b[both])
+            assert ok.all(), (c, a[both][~ok][:3], b[both][~ok][:3])
+    for s, need in (("bazin", 0.75), ("gp2d", 0.93)):
+        if fit_close[s]:
+            close = float(np.concatenate(fit_close[s]).mean())
+            nan_mis = float(np.concatenate(fit_nan[s]).mean())
+            print(s, "share within 1e-4:", close, "NaN-mask mismatch share:", nan_mis)
+            assert close >= need and nan_mis <= 0.01, (s, close, nan_mis)
+
+
+@pytest.mark.parametrize("split", ["train", "test"])
+def test_v34a_and_v92d_matrices_from_device_frames(split):
+    g = fx.load()
+    lc = fx.csr(g, split)
+    ids = [str(i) for i in g[f"{split}_base_ids"]]
+    base, tde, gp2d, bazin = build_caches(lc, ids)
+    # the cache frames have the reference's columns, order, object_id position and integer dtypes
+    for name, fr in (("base", base), ("tde", tde), ("gp2d", gp2d), ("bazin", bazin)):
+        assert list(fr.columns) == [str(c) for c in g[f"{split}_{name}_cols"]], name
+        assert list(fr["object_id"]) == [str(i) for i in g[f"{split}_{name}_ids"]], name
+        ints = [c for c in fr.columns if c != "object_id" and fr[c].dtype == np.int64]
+        assert ints == [str(c) for c in g[f"{split}_{name}_int"]], name
+    X, names, frame = frames.assemble_v34a(base, tde, gp2d, bazin, fx.selection(g))
+    assert names == [str(c) for c in g["v34a_names"]] and X.shape[1] == 224 and X.dtype == np.float64
+    compare_matrix(X, g[f"v34a_X_{split}"], names)
+    X2, names2, _ = frames.assemble_v92d(base, tde, gp2d, bazin, names)
+    assert names2 == [str(c) for c in g["v92d_names"]]
+    compare_matrix(X2, g[f"v92d_X_{split}"], names2)

@@ -201,6 +201,9 @@ def test_fits_golden(name, golden_inputs):
     from conftest import check_fit_parity
     got, st = extract_csr(name, golden_inputs, z=golden_inputs["z"], return_status=True)
     check_fit_parity(got, name, COLUMNS[name])
+    # the converged cost (chi^2 / R^2) and, for Bazin, status + nfev against golden_bazin.npz['nfev']
+    from conftest import check_cost_parity
+    check_cost_parity(got, st, name, golden_inputs)
 
 
 def test_bazin_known_answer(golden_inputs):

@@ -30,6 +30,8 @@ def test_hostsim_fits(name, golden_inputs):
     nst = {"bazin": 12, "powerlaw": 54}[name]
     got, st = hostsim_lib.extract(SET_NAMES.index(name), golden_inputs, golden_inputs["z"], ncol=ncol, nstatus=nst)
     check_fit_parity(got, name, COLUMNS[name])
+    from conftest import check_cost_parity
+    check_cost_parity(got, st, name, golden_inputs)
     # status words: a NaN block <=> status <= 0
     if name == "bazin":
         for k in range(6):
