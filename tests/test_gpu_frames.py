@@ -34,7 +34,9 @@ def build_caches(lc, ids):
 
 
 def set_of(col):
-    for s in ("stat", "color", "shape", "physics", "tde", "gp2d", "bazin"):
+    # the two names that exist twice (temp_stability: colours / TDE, r_bazin_t0: physics / Bazin) reach the model
+    # matrices from the TDE and Bazin caches (the fixture's selection excludes the other two)
+    for s in ("stat", "tde", "bazin", "gp2d", "color", "shape", "physics"):
         if col in COLUMNS[s]:
             return s
     return "meta"
