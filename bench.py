@@ -48,12 +48,22 @@ def _take_objects(lc, n):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sets, lc, budget_s=12.0):
     """Time the oracle (kind "port") on the host cores over a bounded sample of the same workload."""
     import multiprocessing as mp
     import oracle
 
-    cores = min(os.cpu_count() or 1, 16)
+    cores = os.cpu_count() or 1
     n_obj = len(lc["offsets"]) - 1
     pilot = min(6, n_obj)
     small = _take_objects(lc, pilot)
@@ -95,10 +105,32 @@ def cpu_baseline(sets, lc, budget_s=12.0):
         else:
             os.environ[k] = v
     os.unlink(tmp.name)
-    return {"value": sample / dt, "unit": "light curves/s", "cores": cores, "kind": "port",
+    return {"value": sample / dt, "unit": "light curves/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"first {sample} objects of the benchmark batch, sets {'+'.join(sets)}, "
                       f"multiprocessing.Pool({cores}) over the numpy/scipy oracle",
             "single_core_est": 1.0 / per_obj}
+
+
+def local_shard(objects, seed, rank, world, sets):
+    """This rank's shard of ONE synthetic survey of world x `objects` light curves: block b of the survey is
+    make_lightcurves(objects, seed + b) (objects are independent, so the survey is the concatenation of its blocks);
+    the survey is cut into `world` contiguous shards by dist.shard_bounds -- the cost-aware (a N + c N^2 + b N^3)
+    sharding users get from dist.extract_sharded.  A rank generates only the blocks its shard touches.  Per-GPU work
+    stays fixed as world grows: weak scaling.  Returns (csr, bounds, n_local)."""
+    from mallorn_astrophysics_amd import synth
+    from mallorn_astrophysics_amd.dist import shard_bounds
+    n_all = np.concatenate([synth.lengths(objects, seed=seed + b) for b in range(world)])
+    offsets_all = np.concatenate([[0], np.cumsum(n_all)]).astype(np.int64)
+    bounds = shard_bounds(offsets_all, world, sets)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    parts = []
+    for b in range(lo // objects, (max(hi, lo + 1) - 1) // objects + 1):
+        blk = synth.make_lightcurves(objects, seed=seed + b)
+        parts.append(synth.slice_objects(blk, max(lo - b * objects, 0), min(hi - b * objects, objects)))
+    lc = parts[0] if len(parts) == 1 else synth.concat(parts)
+    n_local = hi - lo
+    assert len(lc["offsets"]) - 1 == n_local and np.array_equal(np.diff(lc["offsets"]), n_all[lo:hi])
+    return lc, bounds, n_local
 
 
 def main():
@@ -112,6 +144,19 @@ def main():
     ap.add_argument("--seed", type=int, default=1000000)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD
+        # process (this process has not touched the GPU yet, and never will) and return its exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
     from mallorn_astrophysics_amd import _lib, synth
@@ -121,8 +166,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: a {world}-rank run must not be reported as {a.gpus} GPUs")
     torch.cuda.set_device(local)
     # LCFE_BENCH_FORCE_DIST=1: one-rank rehearsal of the RCCL path on a single-GPU box
     use_dist = world > 1 or os.environ.get("LCFE_BENCH_FORCE_DIST") == "1"
@@ -134,11 +179,12 @@ def main():
     mask = mask_of(sets)
     ncol = int(lib.lcfe_ncols(mask))
 
-    # every rank draws its own shard of the synthetic survey (objects are independent)
-    lc = synth.make_lightcurves(a.objects, seed=a.seed + rank)
+    lc, bounds, n_local = local_shard(a.objects, a.seed, rank, world, sets)
     batch = DeviceBatch(lc, z=lc["z"], device=local)
     # two output buffers: the RCCL gather of step k (its own stream) overlaps the kernels of step k+1
-    outs = [torch.empty((a.objects, ncol), dtype=torch.float64, device=batch.device) for _ in range(2)]
+    # the gather moves equal blocks (RCCL has no ragged gather): every rank pads its rows to the largest shard
+    pad = int(np.diff(bounds).max())
+    outs = [torch.full((pad, ncol), float("nan"), dtype=torch.float64, device=batch.device) for _ in range(2)]
     out = outs[0]
     gathered = [torch.empty_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
     pending = [None, None]
@@ -150,7 +196,7 @@ def main():
         if pending[b] is not None:
             pending[b].wait()                 # the buffer's previous gather has to be done before it is rewritten
             pending[b] = None
-        r = batch.run(mask, out=outs[b], prof=prof)
+        r = batch.run(mask, out=outs[b][:n_local], prof=prof)
         if use_dist:
             pending[b] = dist.gather(outs[b], gathered, dst=0, async_op=True)
         return r[2] if prof else None
@@ -168,7 +214,7 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    note(f"{a.objects} objects/GPU resident, sets {'+'.join(sets)}")
+    note(f"{n_local} objects resident on rank 0 ({a.objects * world} in the survey, {world} shard(s)), sets {'+'.join(sets)}")
     for _ in range(a.warmup):
         step()
     fence()
@@ -196,22 +242,23 @@ def main():
     # roofline), else of the slowest kernel: algorithmic bytes = 25 B/point + 8 B/object offset
     # + 8 B x F output columns, divided by the HIP-event time of that kernel.
     rk = "stat" if "stat" in sets else max(per_set, key=per_set.get)
-    alg_bytes = 25 * n_pts + 8 * (a.objects + 1) + 8 * a.objects * NCOLS[rk] + (8 * a.objects if rk == "physics" else 0)
+    alg_bytes = 25 * n_pts + 8 * (n_local + 1) + 8 * n_local * NCOLS[rk] + (8 * n_local if rk == "physics" else 0)
     achieved = alg_bytes / (per_set[rk] * 1e-3) / 1e9 if per_set[rk] > 0 else 0.0
     # HBM traffic of the roofline kernel from PMC counters (collected offline in separate rocprofv3
     # --pmc passes on this exact workload; bench.py cannot run under the counters itself)
     traffic = None
     tj = os.path.join(ROOT, "profiles", "r01_stat_traffic.json")
-    if rk == "stat" and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
+    if rk == "stat" and world == 1 and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
         traffic = json.load(open(tj)).get("hbm_bytes_per_pass")
     res = {
         "metric": "light curves/sec", "value": a.objects * world * a.steps / dt, "unit": "light curves/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config-5 shard: {'+'.join(sets)} feature sets ({ncol} columns) on "
-                               f"{a.objects} synthetic 6-band light curves per GPU ({n_pts} points on rank 0)",
-                   "objects_per_gpu": a.objects, "sets": sets, "parallelism": f"objects sharded over {world} GPU(s), "
-                   "one RCCL gather of the feature rows per step" if world > 1 else "single GPU"},
+                               f"{a.objects} synthetic 6-band light curves per GPU ({n_local} objects, {n_pts} points on rank 0)",
+                   "objects_per_gpu": a.objects, "survey_objects": a.objects * world, "sets": sets,
+                   "parallelism": (f"one {a.objects * world}-object survey cut into {world} cost-balanced contiguous shards "
+                                   "(dist.shard_bounds), one RCCL gather of the feature rows per step") if world > 1 else "single GPU"},
         "kernel_ms": per_set,
         "kernel_ms_note": ("per-set HIP-event times on one stream (LCFE_SERIAL=1)" if os.environ.get("LCFE_SERIAL") == "1" else
                            "statistics (+ binning) runs alone; the other sets run concurrently on forked streams, "

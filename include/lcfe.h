@@ -109,6 +109,10 @@ int lcfe_extract_device(int mask, int device, void* stream, int64_t n_obj, int64
                         const double* d_z, double* d_out, int32_t* d_status, void* d_workspace,
                         size_t workspace_bytes, lcfe_stats* prof);
 
+/* lcfe_extract keeps its device staging buffers (one set per device, grown on demand) for later calls;
+ * this releases them */
+void lcfe_release_buffers(void);
+
 /* largest number of points per object any kernel tier accepts */
 int64_t lcfe_max_points(void);
 /* mask of the feature sets this build of the library implements */

@@ -1,7 +1,8 @@
 """Multi-GPU sharding of the hot path.
 
 Objects are independent (the reference's extractors are plain loops over objects), so the batch is
-cut into ``world`` contiguous CSR slices balanced by point count, every rank runs the kernels on
+cut into ``world`` contiguous CSR slices balanced by predicted cost (a N + c N^2 + b N^3 per object when the GP is
+on, a N otherwise), every rank runs the kernels on
 its own GPU with no data-path collective, and ONE gather of the ``[n_local, F]`` float64 blocks to
 rank 0 ends the run (``torch.distributed``: backend ``nccl`` = RCCL over xGMI on the GPU node,
 ``gloo`` in the CPU tests).  Contiguous shards keep the original object order, so no permutation
@@ -12,21 +13,53 @@ from __future__ import annotations
 import numpy as np
 
 
-def shard_bounds(offsets, world: int):
-    """Object index bounds [b_0=0, b_1, ..., b_world=n_obj] of ``world`` contiguous shards with
-    (nearly) equal numbers of POINTS -- the cost of every kernel grows with the point count."""
+# Cost model of one object with N rows, in GPU-seconds of one MI355X (a N + b N^3 when the GP is on;
+# an N^2 term covers the latency-bound part of the small GP tiers).  Coefficients fitted to the per-tier kernel
+# times of profiles/r02_bench_serial_kernel_stats.csv (125,000 objects): streaming sets + bounded fits 1.14 s per
+# 16.95 M points; GP tiers 64/112/160/240/512 rows: 0.022/0.16/0.34/0.48/0.80 s for 13/42/34/25/10 k objects.
+COST_POINT = 6.7e-8
+COST_GP_N2 = 4.1e-10
+COST_GP_N3 = 1.15e-12
+GP_SETS = ("gp2d", "gp1d")
+
+
+def object_costs(offsets, sets=None):
+    """Predicted cost of every object for the feature sets `sets` (None = the full v34a/v55 workload)."""
+    n = np.diff(np.asarray(offsets, np.int64)).astype(np.float64)
+    cost = COST_POINT * n
+    if sets is None or any(s in GP_SETS for s in ([sets] if isinstance(sets, str) else sets)):
+        cost = cost + COST_GP_N2 * n * n + COST_GP_N3 * n * n * n
+    return cost
+
+
+def shard_bounds(offsets, world: int, sets=None, cost=None):
+    """Object index bounds [b_0=0, b_1, ..., b_world=n_obj] of ``world`` contiguous shards with (nearly) equal
+    predicted COST: a N per object for the streaming sets and the bounded fits, plus c N^2 + b N^3 when a GP set
+    is among ``sets`` -- the heavy N^3 tail of the Gram-matrix factorisations decides the slowest rank, not the
+    point count.  ``cost`` overrides the model with explicit per-object costs."""
     offsets = np.asarray(offsets, np.int64)
     n_obj = len(offsets) - 1
-    total = int(offsets[-1])
-    targets = (np.arange(1, world) * total) // max(world, 1)
-    cuts = np.searchsorted(offsets[1:], targets, side="left") + 1 if n_obj else np.zeros(world - 1, np.int64)
+    if n_obj <= 0:
+        return np.zeros(world + 1, np.int64)
+    c = object_costs(offsets, sets) if cost is None else np.asarray(cost, np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(c)])
+    total = cum[-1]
+    if total <= 0:                                          # all-empty objects: split by count
+        cuts = (np.arange(1, world) * n_obj) // world
+    else:
+        targets = np.arange(1, world) * (total / world)
+        # the boundary whose cumulative cost is nearest to the target
+        hi = np.searchsorted(cum, targets, side="left")
+        hi = np.clip(hi, 1, n_obj)
+        lo = hi - 1
+        cuts = np.where(np.abs(cum[lo] - targets) <= np.abs(cum[hi] - targets), lo, hi)
     b = np.concatenate([[0], np.minimum(cuts, n_obj), [n_obj]]).astype(np.int64)
     return np.maximum.accumulate(b)
 
 
-def shard_csr(csr, rank: int, world: int, z=None):
+def shard_csr(csr, rank: int, world: int, z=None, sets=None):
     """The CSR slice (and redshifts) of ``rank``; ``(sub_csr, sub_z, (lo, hi))``."""
-    b = shard_bounds(csr["offsets"], world)
+    b = shard_bounds(csr["offsets"], world, sets)
     lo, hi = int(b[rank]), int(b[rank + 1])
     off = np.asarray(csr["offsets"], np.int64)
     s, e = int(off[lo]), int(off[hi])
@@ -76,8 +109,8 @@ def extract_sharded(sets, csr, z=None, group=None):
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    bounds = shard_bounds(csr["offsets"], world)
-    sub, sub_z, _ = shard_csr(csr, rank, world, z)
+    bounds = shard_bounds(csr["offsets"], world, sets)
+    sub, sub_z, _ = shard_csr(csr, rank, world, z, sets)
     batch = DeviceBatch(sub, z=sub_z, device=torch.cuda.current_device())
     out, _ = batch.run(sets)
     full = gather_rows(out, len(csr["offsets"]) - 1, bounds, group=group)

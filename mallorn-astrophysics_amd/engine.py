@@ -46,8 +46,6 @@ def extract_csr(sets, csr, z=None, device=-1, return_status=False, return_prof=F
     lib = _lib.load()
     mask = mask_of(sets)
     n_obj, total = check_csr(csr)
-    if total and int(np.diff(csr["offsets"]).max()) > lib.lcfe_max_points():
-        pass  # longer objects get NaN rows + status -100 (documented limit of the LDS tiers)
     ncol = lib.lcfe_ncols(mask)
     nst = lib.lcfe_nstatus(mask)
     out = np.full((n_obj, ncol), np.nan)
@@ -80,13 +78,17 @@ class DeviceBatch:
 
         self.torch = torch
         n_obj, total = check_csr(csr)
+        if z is not None:
+            z = np.ascontiguousarray(z, np.float64)
+            if z.shape != (n_obj,):                 # the physics kernels read z[i] for every object
+                raise ValueError(f"z must have one entry per object: shape {z.shape}, expected ({n_obj},)")
         self.n_obj, self.n_points = n_obj, total
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.max_len = int(np.diff(csr["offsets"]).max()) if n_obj else 0
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         self.offsets = to(csr["offsets"])
         self.t, self.flux, self.err, self.band = to(csr["t"]), to(csr["flux"]), to(csr["err"]), to(csr["band"])
-        self.z = None if z is None else to(np.asarray(z, np.float64))
+        self.z = None if z is None else to(z)
         self._ws = None
 
     def run(self, sets, out=None, status=None, prof=False):
@@ -99,7 +101,13 @@ class DeviceBatch:
             out = torch.empty((self.n_obj, ncol), dtype=torch.float64, device=self.device)
         if status is None and nst:
             status = torch.zeros((self.n_obj, nst), dtype=torch.int32, device=self.device)
-        assert out.is_contiguous() and out.shape == (self.n_obj, ncol) and out.dtype == torch.float64
+        # a malformed buffer must never reach a kernel (an out-of-bounds access can reset the GPU)
+        if not (out.is_contiguous() and tuple(out.shape) == (self.n_obj, ncol) and out.dtype == torch.float64
+                and out.device == self.device):
+            raise ValueError(f"out must be a contiguous float64 [{self.n_obj}, {ncol}] tensor on {self.device}")
+        if nst and not (status.is_contiguous() and tuple(status.shape) == (self.n_obj, nst)
+                        and status.dtype == torch.int32 and status.device == self.device):
+            raise ValueError(f"status must be a contiguous int32 [{self.n_obj}, {nst}] tensor on {self.device}")
         wsb = lib.lcfe_workspace_bytes(mask, self.n_obj, self.n_points)
         if self._ws is None or self._ws.numel() < wsb:
             self._ws = torch.empty(int(wsb), dtype=torch.uint8, device=self.device)

@@ -100,6 +100,26 @@ def make_lightcurves(n_obj: int, seed: int | None = None, n_min: int = 12, n_max
             "z": z, "ebv": ebv, "cls": cls}
 
 
+def lengths(n_obj: int, seed: int | None = None, n_min: int = 12, n_max: int = 500, n_median: float = 120.0):
+    """Row counts of the objects :func:`make_lightcurves` draws for the same arguments (its first random draw),
+    without generating the light curves: lets a rank of a sharded run locate its objects in a large survey."""
+    rng = np.random.default_rng(n_obj if seed is None else seed)
+    return np.clip(np.rint(rng.lognormal(np.log(n_median), 0.5, n_obj)), n_min, n_max).astype(np.int64)
+
+
+def slice_objects(lc: dict, lo: int, hi: int):
+    """Objects [lo, hi) of a CSR dict as a CSR dict of their own (contiguous slice, no copy of the other rows)."""
+    off = np.asarray(lc["offsets"], np.int64)
+    s, e = int(off[lo]), int(off[hi])
+    out = {"offsets": np.ascontiguousarray(off[lo:hi + 1] - s)}
+    for k in ("t", "flux", "err", "band"):
+        out[k] = np.ascontiguousarray(lc[k][s:e])
+    for k in ("z", "ebv", "cls"):
+        if k in lc:
+            out[k] = np.ascontiguousarray(np.asarray(lc[k])[lo:hi])
+    return out
+
+
 def object_ids(n_obj: int, prefix: str = "obj"):
     return [f"{prefix}_{i:07d}" for i in range(n_obj)]
 

@@ -385,3 +385,37 @@ def test_full_size_properties():
     assert np.array_equal(nobs, np.round(nobs))
     assert np.array_equal(nobs.sum(1), a[:, cols.index("all_n_obs")])
     assert np.array_equal(a[:, cols.index("all_n_obs")], np.diff(lc["offsets"]).astype(float))
+
+
+def test_device_batch_validates_out_and_status_buffers():
+    """DeviceBatch.run: wrong shape / dtype / device of a caller-supplied buffer raises instead of reaching a kernel."""
+    import torch
+    from mallorn_astrophysics_amd.engine import DeviceBatch
+    lc = synth.make_lightcurves(20, seed=4)
+    db = DeviceBatch(lc, z=lc["z"], device=0)
+    with pytest.raises(ValueError):
+        db.run("stat", out=torch.empty((20, 100), dtype=torch.float64, device=db.device))
+    with pytest.raises(ValueError):
+        db.run("stat", out=torch.empty((20, 123), dtype=torch.float32, device=db.device))
+    with pytest.raises(ValueError):
+        db.run("stat", out=torch.empty((20, 123), dtype=torch.float64))            # host tensor
+    with pytest.raises(ValueError):
+        db.run("bazin", status=torch.zeros((20, 11), dtype=torch.int32, device=db.device))
+    with pytest.raises(ValueError):
+        db.run("bazin", status=torch.zeros((20, 12), dtype=torch.int64, device=db.device))
+
+
+def test_over_long_objects_are_reported_not_silent():
+    """The DataFrame wrappers warn (count + ids) about objects beyond a set's largest tier: their NaN rows would
+    otherwise look like failed fits (the reference has no such limit)."""
+    from mallorn_astrophysics_amd.features.bazin_fitting import extract_bazin_features
+    rng = np.random.default_rng(12)
+    objs = []
+    for n in (60, 1100):
+        t = np.sort(59000 + rng.uniform(0, 400, n))
+        objs.append((t, rng.normal(10, 3, n), np.full(n, 1.0), rng.choice(6, n)))
+    lc = synth.from_objects(objs)
+    df, _ = synth.to_dataframe(lc, ["short", "long"])
+    with pytest.warns(RuntimeWarning, match="long"):
+        out = extract_bazin_features(df, ["short", "long"])
+    assert np.isnan(out[COLUMNS["bazin"]].to_numpy(float)[1]).all()
