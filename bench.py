@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NCOLS = {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65, "physics": 32, "gp2d": 27,
-         "gp1d": 21}
+         "gp1d": 21, "research": 40}
 
 
 _CPU_LC = None      # sample batch of a CPU-baseline worker
@@ -48,6 +48,29 @@ def _take_objects(lc, n):
     return out
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity mask and the cgroup CPU quota of the box
+    (a GPU box hands a one-GPU job a share of the host, e.g. 16 of its cores), not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -63,7 +86,7 @@ def cpu_baseline(sets, lc, budget_s=12.0):
     import multiprocessing as mp
     import oracle
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n_obj = len(lc["offsets"]) - 1
     pilot = min(6, n_obj)
     small = _take_objects(lc, pilot)

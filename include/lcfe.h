@@ -43,7 +43,9 @@ enum {
     LCFE_SET_PHYSICS = 6,  /* physics_based.py:292-502       32 columns */
     LCFE_SET_GP2D = 7,     /* multiband_gp.py:292-385        27 columns */
     LCFE_SET_GP1D = 8,     /* gaussian_process.py:173-310    21 columns (per-band scikit-learn GP) */
-    LCFE_NUM_SETS = 9
+    LCFE_SET_RESEARCH = 9, /* research_features.py:533-600   40 columns (v115: log-log power law, nuclear proxy,
+                              colour at peak, Mexican-hat power spectra, luminosity; reads z) */
+    LCFE_NUM_SETS = 10
 };
 #define LCFE_MASK(id) (1 << (id))
 #define LCFE_MASK_ALL ((1 << LCFE_NUM_SETS) - 1)
@@ -83,7 +85,7 @@ int64_t lcfe_nstatus(int mask);
  * (-1 = current device), runs the kernels of every set in `mask`, copies results back.
  *   offsets  int64[n_obj+1], offsets[0] == 0, non-decreasing
  *   t, flux, err  float64[offsets[n_obj]]   band  uint8[offsets[n_obj]]
- *   z        float64[n_obj] redshift (used by LCFE_SET_PHYSICS only; NULL or NaN entries = 0,
+ *   z        float64[n_obj] redshift (used by LCFE_SET_PHYSICS and LCFE_SET_RESEARCH; NULL or NaN entries = 0,
  *            physics_based.py:348)
  *   out      float64[n_obj * lcfe_ncols(mask)] row-major
  *   status   int32[n_obj * lcfe_nstatus(mask)] or NULL

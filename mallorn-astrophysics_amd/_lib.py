@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCFE_LIB_PATH") or os.path.join(_HERE, "csrc", "liblcfe.so")   # override: instrumented builds
-NUM_SETS = 9
+NUM_SETS = 10
 
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_f64p = ctypes.POINTER(ctypes.c_double)

@@ -10,8 +10,8 @@ The integer ids / bit masks below are the same constants as ``include/lcfe.h``.
 BANDS = ["u", "g", "r", "i", "z", "y"]
 
 # feature-set ids (bit = 1 << id) -- keep in sync with include/lcfe.h
-SET_STAT, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D = range(9)
-SET_NAMES = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d", "gp1d"]
+SET_STAT, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D, SET_RESEARCH = range(10)
+SET_NAMES = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d", "gp1d", "research"]
 
 _STAT17 = ["n_obs", "mean", "std", "min", "max", "median", "skew", "kurtosis", "amplitude", "mad",
            "iqr", "beyond_1std", "beyond_2std", "max_slope", "mean_snr", "time_span", "cadence_mean"]
@@ -129,11 +129,26 @@ def _gp1d():
                    "gp_mean_amplitude"]
 
 
+def _research():
+    # research_features.py:57-64,150-158,175-180,265-269,371-375,472-478 (the v115 "research" features)
+    pl = ["powerlaw_alpha", "powerlaw_alpha_deviation_53", "powerlaw_alpha_deviation_512", "powerlaw_chi2",
+          "powerlaw_residual_std", "powerlaw_fit_success"]
+    cols = [f"{b}_{k}" for b in "gri" for k in pl]
+    cols += ["optical_mean_powerlaw_alpha", "optical_std_powerlaw_alpha", "optical_mean_deviation_53"]
+    cols += ["nuclear_smoothness", "nuclear_concentration", "nuclear_variability_ratio", "nuclear_position_score"]
+    cols += ["g_r_color_at_peak", "g_r_color_peak_to_late", "r_i_color_at_peak", "r_i_color_peak_to_late"]
+    cols += ["mhps_10d", "mhps_30d", "mhps_100d", "mhps_10_100_ratio", "mhps_30_100_ratio", "mhps_dominant_scale"]
+    cols += ["luminosity_distance_mpc", "peak_luminosity", "luminosity_amplitude", "mean_luminosity",
+             "luminosity_decline_rate"]
+    return cols
+
+
 COLUMNS = {"stat": _stat(), "bazin": _bazin(), "powerlaw": _powerlaw(), "tde": _tde(),
-           "color": _color(), "shape": _shape(), "physics": _physics(), "gp2d": _gp2d(), "gp1d": _gp1d()}
+           "color": _color(), "shape": _shape(), "physics": _physics(), "gp2d": _gp2d(), "gp1d": _gp1d(),
+           "research": _research()}
 NCOLS = {k: len(v) for k, v in COLUMNS.items()}
 assert NCOLS == {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65,
-                 "physics": 32, "gp2d": 27, "gp1d": 21}, NCOLS
+                 "physics": 32, "gp2d": 27, "gp1d": 21, "research": 40}, NCOLS
 
 # integer-valued columns of the statistics frame (int64 in the reference's DataFrame)
 STAT_INT_COLUMNS = [f"{p}_n_obs" for p in BANDS + ["all"]] + ["peak_band"]

@@ -9,10 +9,11 @@
 #include "shape.hpp"
 #include "physics.hpp"
 #include "gp.hpp"
+#include "research.hpp"
 
 namespace lcfe {
 
-enum { SET_STAT = 0, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D, NUM_SETS };
+enum { SET_STAT = 0, SET_BAZIN, SET_POWERLAW, SET_TDE, SET_COLOR, SET_SHAPE, SET_PHYSICS, SET_GP2D, SET_GP1D, SET_RESEARCH, NUM_SETS };
 
 LCFE_HD int set_ncols(int set) {
     switch (set) {
@@ -25,6 +26,7 @@ LCFE_HD int set_ncols(int set) {
         case SET_PHYSICS: return 32;
         case SET_GP2D: return 27;
         case SET_GP1D: return 21;
+        case SET_RESEARCH: return 40;
     }
     return 0;
 }
@@ -38,6 +40,7 @@ LCFE_HD int set_nstatus(int set) {
         case SET_GP2D: return 4;
 #endif
         case SET_GP1D: return 4;
+        case SET_RESEARCH: return 1;
     }
     return 0;
 }
@@ -83,6 +86,12 @@ template <int CAP>
 struct SetLds<SET_PHYSICS, CAP> {
     ObjLds<CAP> obj;
     PhysicsLds<CAP> s;
+};
+
+template <int CAP>
+struct SetLds<SET_RESEARCH, CAP> {
+    ObjLds<CAP> obj;
+    ResearchLds<CAP> s;
 };
 
 // copy `ncol` wave-shared doubles to the object's output row (coalesced on the device)
@@ -174,6 +183,17 @@ struct RunSet<W, SET_PHYSICS, CAP> {
         stage_object<W, CAP>(in, ws.obj);
         physics_object<W, CAP>(ws.obj, in.z, ws.s);
         store_row<W>(ws.s.out, row, PHYSICS_NCOL);
+        W::sync();
+    }
+};
+
+template <class W, int CAP>
+struct RunSet<W, SET_RESEARCH, CAP> {
+    static LCFE_FN void run(const ObjIn& in, SetLds<SET_RESEARCH, CAP>& ws, double* row, int32_t* st) {
+        stage_object<W, CAP>(in, ws.obj);
+        const int rc = research_object<W, CAP>(ws.obj, in.z, ws.s);
+        if (st && W::lane() == 0) st[0] = rc;
+        store_row<W>(ws.s.out, row, RESEARCH_NCOL);
         W::sync();
     }
 };

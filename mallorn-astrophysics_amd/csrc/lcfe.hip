@@ -577,7 +577,7 @@ int launch_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, dou
 // largest LDS tier a set's working memory fits in (160 KiB per workgroup)
 template <int SET>
 constexpr int max_tier() {
-    return (SET == SET_BAZIN || SET == SET_POWERLAW) ? 3 : 4;
+    return (SET == SET_BAZIN || SET == SET_POWERLAW || SET == SET_RESEARCH) ? 3 : 4;
 }
 
 template <int SET>
@@ -816,7 +816,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         switch (s) {
             case SET_BAZIN: return side[0];
             case SET_POWERLAW: return side[1];
-            case SET_TDE: case SET_COLOR: case SET_SHAPE: case SET_PHYSICS: case SET_GP1D: return side[2];
+            case SET_TDE: case SET_COLOR: case SET_SHAPE: case SET_PHYSICS: case SET_GP1D: case SET_RESEARCH: return side[2];
             default: return stream;
         }
     };
@@ -872,6 +872,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_RESEARCH: rc = launch_set<SET_RESEARCH>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_GP2D:
                 if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }

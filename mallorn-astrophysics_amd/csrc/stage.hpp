@@ -169,8 +169,10 @@ LCFE_FN void sort_flip_step(double (&v)[KPL]) {
         double p[KPL];
 #pragma unroll
         for (int r = 0; r < KPL; ++r) p[r] = W::template xfetch<ML>(v[KPL - 1 - r]);
+        // one compare + select instead of min, max and a select: the partner replaces the own value where
+        // "partner < own" agrees with "this lane keeps the minimum" (NaN-free data; equal values may swap freely)
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) { const double lo = dmin(v[r], p[r]), hi = dmax(v[r], p[r]); v[r] = keep_min ? lo : hi; }
+        for (int r = 0; r < KPL; ++r) v[r] = ((p[r] < v[r]) == keep_min) ? p[r] : v[r];
     }
 }
 template <class W, int KPL, int J>
@@ -187,7 +189,7 @@ LCFE_FN void sort_half_steps(double (&v)[KPL]) {
 #pragma unroll
             for (int r = 0; r < KPL; ++r) p[r] = W::template xfetch<ML>(v[r]);
 #pragma unroll
-            for (int r = 0; r < KPL; ++r) { const double lo = dmin(v[r], p[r]), hi = dmax(v[r], p[r]); v[r] = keep_min ? lo : hi; }
+            for (int r = 0; r < KPL; ++r) v[r] = ((p[r] < v[r]) == keep_min) ? p[r] : v[r];
         }
         sort_half_steps<W, KPL, J / 2>(v);
     }

@@ -25,6 +25,8 @@
 namespace lcfe {
 
 #if defined(__HIPCC__)
+// (DPP moves use __builtin_amdgcn_mov_dpp with bound_ctrl: every pattern used here reads a valid lane, and the
+// update_dpp form makes the compiler copy the source into the destination first -- two moves per dword.)
 // Value held by lane (l ^ MASK) of the same wavefront, MASK a compile-time constant < 64.  Register
 // moves (DPP) where a DPP pattern is an XOR (1, 2, 3 = quad_perm; 7 = row_half_mirror; 8 = row_ror:8;
 // 15 = row_mirror), the LDS crossbar without memory traffic otherwise (ds_swizzle inside 32 lanes,
@@ -32,12 +34,12 @@ namespace lcfe {
 template <int MASK>
 __device__ __forceinline__ int lane_xor_fetch(int v) {
     static_assert(MASK > 0 && MASK < 64, "lane mask");
-    if constexpr (MASK == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
-    else if constexpr (MASK == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
-    else if constexpr (MASK == 3) return __builtin_amdgcn_update_dpp(v, v, 0x1B, 0xf, 0xf, false);
-    else if constexpr (MASK == 7) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
-    else if constexpr (MASK == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
-    else if constexpr (MASK == 15) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (MASK == 3) return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true);
+    else if constexpr (MASK == 7) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
+    else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);
+    else if constexpr (MASK == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);
     else if constexpr (MASK < 32) return __builtin_amdgcn_ds_swizzle(v, 0x1f | (MASK << 10));
     else return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ MASK) << 2), v);
 }
@@ -89,12 +91,12 @@ struct WaveDev {
     static __device__ __forceinline__ double dpp(double v) {
         const long long b = __builtin_bit_cast(long long, v);
         int lo = (int)b, hi = (int)(b >> 32);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
     template <int CTRL>
-    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
     static __device__ __forceinline__ double rdlane(double v, int l) {
         const long long b = __builtin_bit_cast(long long, v);
         const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
@@ -155,12 +157,12 @@ struct GroupDev {
     static __device__ __forceinline__ double dpp(double v) {
         const long long b = __builtin_bit_cast(long long, v);
         int lo = (int)b, hi = (int)(b >> 32);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
     template <int CTRL>
-    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+    static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
     // quad_perm(1,0,3,2) = 0xB1, quad_perm(2,3,0,1) = 0x4E, row_half_mirror = 0x141
     template <class V, class Op>
     static __device__ __forceinline__ V reduce(V v, Op op) {

@@ -1,12 +1,13 @@
 """Batch driver of the oracle: CSR arrays in, [n_obj, ncols] float64 out."""
 import numpy as np
 
-from . import bazin, color, gp1d, gp2d, physics, powerlaw, shape, stat, tde
+from . import bazin, color, gp1d, gp2d, physics, powerlaw, research, shape, stat, tde
 from .common import iter_objects
 
 _MODS = {"stat": stat, "bazin": bazin, "powerlaw": powerlaw, "tde": tde, "color": color,
          "shape": shape, "physics": physics, "gp2d": gp2d,
-         "gp1d": gp1d}           # per-band scikit-learn GP: oracle only so far
+         "gp1d": gp1d,           # per-band scikit-learn GP
+         "research": research}   # v115 research features
 NCOLS = {k: m.NCOL for k, m in _MODS.items()}
 
 

@@ -80,6 +80,7 @@ extern "C" int hostsim_extract(int set, int64_t n_obj, const int64_t* offsets, c
         case SET_COLOR: run_all<SET_COLOR>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_SHAPE: run_all<SET_SHAPE>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_PHYSICS: run_all<SET_PHYSICS>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
+        case SET_RESEARCH: run_all<SET_RESEARCH>(n_obj, offsets, t, flux, err, band, z, out, status); return 0;
         case SET_GP2D: run_gp(n_obj, offsets, t, flux, err, band, out, status); return 0;
         default: return 1;
     }

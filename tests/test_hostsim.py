@@ -11,7 +11,8 @@ from mallorn_astrophysics_amd.columns import COLUMNS, SET_NAMES, STAT_INT_COLUMN
 
 # relative tolerance per set (floats); near-zero moments get an absolute floor
 TOL = {"stat": dict(rtol=1e-9, atol=1e-12), "tde": dict(rtol=1e-9, atol=1e-8), "color": dict(rtol=1e-9, atol=1e-10),
-       "shape": dict(rtol=1e-9, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10)}
+       "shape": dict(rtol=1e-9, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10),
+       "research": dict(rtol=1e-8, atol=1e-9)}
 
 
 @pytest.mark.parametrize("name", list(TOL))
