@@ -48,12 +48,21 @@ LCFE_HD constexpr int gp_panel_ld(int np) { return ((np % 32) == 16) ? np : np +
 // Working memory of one object; NP = capacity in rows (valid points + the augmented residual row).  The
 // tile-packed matrix itself lives in LDS for the small tiers and in a per-workgroup slab of global scratch
 // otherwise.
-template <int NP, int NW = 4>
+// second pivot panel + pivot inverse of the fused (two pivot tiles per pass) sweep of the global-scratch tiers
+template <int NP, bool FUSE> struct GpFusePanels {};
+template <int NP> struct GpFusePanels<NP, true> {
+    double V2[GP_B][gp_panel_ld(NP)];
+    double P2[GP_B][GP_B];
+};
+
+template <int NP, int NW = 4, bool FUSE = false>
 struct GpLds {
+    static constexpr bool kFuse = FUSE;
     double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
     double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
     double V[GP_B][gp_panel_ld(NP)];          // pivot-tile columns A(:, P) (rows p >= bs of a partial block are zero)
     double P[GP_B][GP_B];                     // inverse of the (identity-padded) pivot block
+    GpFusePanels<NP, FUSE> fz;
     LbState<4, 10> lb;                        // L-BFGS-B state machine: advanced by thread 0 between two barriers
     int lb_why;
     double slot[2];
@@ -150,22 +159,22 @@ LCFE_FN int gp_row_owner(int i, int nt, int nw) {
 // registers in A-operand layout and is used at once, never stored as a panel --, writes it into the pivot
 // column / row tiles, and applies C_ij -= W_i V_j' to its tiles (four v_mfma_f64_16x16x4_f64 per tile, four
 // tiles in flight).  Three workgroup barriers per step, no per-element index arithmetic.
-template <class W, int NP, class KP>
-LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logdet) {
+template <class W, int NP, class KP, class LDS>
+LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
     const int nrow = n + 1;
     const int nt = (nrow + 15) >> 4;
 #if defined(__HIPCC__)
     if constexpr (W::WAVE == 64) {
         constexpr int NW = W::NWAVES;
+        constexpr int LDV = gp_panel_ld(NP);
         const int l = W::wlane(), lr = l >> 4, lc = l & 15, w = W::wave_id();
         double ld = 0.0, prod = 1.0;          // wavefront 0: exponent sum and mantissa product of the pivots
-        bool bad_acc = false;
-        for (int kt = 0, k0 = 0; k0 < n; ++kt, k0 += GP_B) {
-            const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
-            GP_T0();
-            // (1) pivot tile column -> V[p][i] = A(i, k0 + p); rows p >= bs of the panel are zero.  Tiles below the
-            //     pivot are copied (transposed) by the owner of their row, the tiles of the pivot row itself by all
-            //     wavefronts in turn; two tiles per trip so that their loads overlap.
+
+        // (1) pivot tile column kt -> Vp[p][i] = A(i, 16 kt + p); rows p >= bs of the panel are zero.  Tiles below the
+        //     pivot are copied (transposed) by the owner of their row, the tiles of the pivot row itself by all
+        //     wavefronts in turn; two tiles per trip so that their loads overlap.
+        auto gather = [&](double (*Vp)[LDV], int kt, int bs) {
+            const int k0 = kt << 4;
             for (int blk = 0;; blk += 2) {
                 int ii[2];
                 double x[2][4];
@@ -181,7 +190,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
                 for (int u = 0; u < 2; ++u)
                     if (ii[u] > kt) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) S.V[lc][(ii[u] << 4) + lr + 4 * v] = (lc < bs) ? x[u][v] : 0.0;
+                        for (int v = 0; v < 4; ++v) Vp[lc][(ii[u] << 4) + lr + 4 * v] = (lc < bs) ? x[u][v] : 0.0;
                     }
                 if (ii[1] <= kt) break;
             }
@@ -199,7 +208,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
                     const int j = j0 + u * NW;
                     if (j < kt) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) S.V[lr + 4 * v][(j << 4) + lc] = (lr + 4 * v < bs) ? x[u][v] : 0.0;
+                        for (int v = 0; v < 4; ++v) Vp[lr + 4 * v][(j << 4) + lc] = (lr + 4 * v < bs) ? x[u][v] : 0.0;
                     }
                 }
             }
@@ -207,30 +216,207 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
                 KP T = A + tile_base(kt, kt);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int pp = lr + 4 * v;                           // V[pp][k0 + lc] = A(k0 + lc, k0 + pp), symmetric
+                    const int pp = lr + 4 * v;                           // Vp[pp][k0 + lc] = A(k0 + lc, k0 + pp), symmetric
                     const double x = (lc >= pp) ? T[(lc << 4) + pp] : T[(pp << 4) + lc];
-                    S.V[pp][k0 + lc] = (pp < bs) ? x : 0.0;
+                    Vp[pp][k0 + lc] = (pp < bs) ? x : 0.0;
                 }
             }
+        };
+        // (2) wavefront 0: D^-1 of the identity-padded pivot block of panel Vp, Gauss-Jordan in registers -> Pp
+        auto invert = [&](double (*Vp)[LDV], double (*Pp)[GP_B], int k0, int bs) {
+            if (w != 0) return;
+            const int a = l >> 2, c = l & 3;
+            double p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 4 * c + r;
+                p[r] = (a < bs && b < bs) ? Vp[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
+            }
+            bool bad = false;
+            gp_inv16_pivots<0>(p, a, c, bad, prod, ld);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pp[a][4 * c + r] = -p[r];         // the sweep leaves -D^-1
+            if (bad && l == 0) S.pivot_bad = 1;
+        };
+        // W_i' = D^-1 V_i'  ->  register v of lane l = W_i(row lc, k = 4 v + lr): the A operand of the updates
+        auto w_alayout = [&](const double (&dA)[4], double (*Vp)[LDV], int i) {
+            gp_v4f64 wt = {0, 0, 0, 0};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wt = __builtin_amdgcn_mfma_f64_16x16x4f64(dA[kc], Vp[4 * kc + lr][(i << 4) + lc], wt, 0, 0, 0);
+            return wt;
+        };
+        // the same numbers in D (tile) layout: register v of lane l = W_i(row lr + 4 v, col lc)
+        auto w_dlayout = [&](const double (&dA)[4], double (*Vp)[LDV], int i) {
+            gp_v4f64 wd = {0, 0, 0, 0};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wd = __builtin_amdgcn_mfma_f64_16x16x4f64(Vp[4 * kc + lr][(i << 4) + lc], dA[kc], wd, 0, 0, 0);
+            return wd;
+        };
+
+        int kt = 0, k0 = 0;
+        while (k0 < n) {
+            if constexpr (LDS::kFuse) {
+                if (k0 + 2 * GP_B <= n) {
+                    // ===== two full pivot tiles a = kt, b = kt + 1 in ONE pass over the matrix (the global-scratch tiers are
+                    // bound by the traffic of that pass, not by the MFMAs): step a is first applied to tile column b and tile
+                    // row b only, which gives the second panel; then every other tile takes both rank-16 updates at once.
+                    // Operation for operation the same arithmetic as two single steps.
+                    const int a = kt, b = kt + 1;
+                    auto& V2 = S.fz.V2;
+                    auto& P2 = S.fz.P2;
+                    GP_T0();
+                    gather(S.V, a, GP_B);
+                    if (W::lane() == 0) S.pivot_bad = 0;
+                    W::sync();
+                    GP_T(0);
+                    invert(S.V, S.P, k0, GP_B);
+                    W::sync();
+                    if (S.pivot_bad != 0) return false;
+                    GP_T(1);
+                    double dA1[4];
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) dA1[kc] = S.P[lc][4 * kc + lr];
+                    // ---- step a on tile column b (rows i > b, by their owners) ...
+                    for (int blk = 0;; ++blk) {
+                        const int pos = (blk & 1) ? NW - 1 - w : w;
+                        const int i = nt - 1 - (blk * NW + pos);
+                        if (i <= b) break;
+                        const gp_v4f64 wt = w_alayout(dA1, S.V, i);
+                        KP T = A + tile_base(i, b);
+                        gp_v4f64 c;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) c[v] = T[((lr + 4 * v) << 4) + lc];
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc)
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-wt[kc], S.V[4 * kc + lr][(b << 4) + lc], c, 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+                    }
+                    // ---- ... and on tile row b, its b + 1 tiles dealt to all wavefronts
+                    {
+                        const gp_v4f64 wtb = w_alayout(dA1, S.V, b);
+                        for (int j = w; j <= b; j += NW) {
+                            KP T = A + tile_base(b, j);
+                            gp_v4f64 c;
+                            if (j == a) c = w_dlayout(dA1, S.V, b);        // pivot column of step a: A(b-rows, a-cols) <- W_b
+                            else {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) c[v] = T[((lr + 4 * v) << 4) + lc];
+#pragma unroll
+                                for (int kc = 0; kc < 4; ++kc)
+                                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-wtb[kc], S.V[4 * kc + lr][(j << 4) + lc], c, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+                        }
+                    }
+                    W::sync();
+                    gather(V2, b, GP_B);
+                    W::sync();
+                    invert(V2, P2, k0 + GP_B, GP_B);
+                    W::sync();
+                    if (S.pivot_bad != 0) return false;
+                    GP_T(2);
+                    double dA2[4];
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) dA2[kc] = P2[lc][4 * kc + lr];
+                    // ---- both updates on every other tile, row by row
+                    for (int blk = 0;; ++blk) {
+                        const int pos = (blk & 1) ? NW - 1 - w : w;
+                        const int i = nt - 1 - (blk * NW + pos);
+                        if (i < 0) break;
+                        if (i == b) {
+                            // pivot row of step b: off-diagonal tiles come from the owners of the rows j < b (below)
+                            KP T = A + tile_base(b, b);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = -P2[lr + 4 * v][lc];
+                            continue;
+                        }
+                        const gp_v4f64 w2 = w_alayout(dA2, V2, i);
+                        if (i > b) {
+                            KP T = A + tile_base(i, b);                   // A(16 i + lc, 16 b + k) <- W2_i(lc, k)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) T[(lc << 4) + 4 * v + lr] = w2[v];
+                        } else {
+                            KP T = A + tile_base(b, i);                   // A(16 b + k, 16 i + lc) <- W2_i(lc, k)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) T[((4 * v + lr) << 4) + lc] = w2[v];
+                        }
+                        const double n2[4] = {-w2[0], -w2[1], -w2[2], -w2[3]};
+                        if (i == a) {
+                            // pivot row of step a: tile (a, j) holds W1_j' (-D1^-1 on the diagonal) before step b touches it
+                            for (int j = 0; j <= a; ++j) {
+                                gp_v4f64 c;
+                                if (j == a) {
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) c[v] = -S.P[lr + 4 * v][lc];
+                                } else c = w_alayout(dA1, S.V, j);       // element (k, col) of the tile = W1_j(col, k)
+#pragma unroll
+                                for (int kc = 0; kc < 4; ++kc)
+                                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(n2[kc], V2[4 * kc + lr][(j << 4) + lc], c, 0, 0, 0);
+                                KP T = A + tile_base(a, j);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+                            }
+                            continue;
+                        }
+                        const gp_v4f64 w1 = w_alayout(dA1, S.V, i);
+                        const double n1[4] = {-w1[0], -w1[1], -w1[2], -w1[3]};
+                        constexpr int UNR = 2;
+                        for (int j0 = 0; j0 <= i; j0 += UNR) {
+                            gp_v4f64 c[UNR];
+                            double b1[UNR][4], b2[UNR][4];
+                            bool on[UNR], col_a[UNR];
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                const int j = j0 + u;
+                                on[u] = (j <= i) && (j != b);
+                                col_a[u] = (j == a);
+                                const int jj = (j <= i) ? j : i;
+                                KP T = A + tile_base(i, jj);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) c[u][v] = T[((lr + 4 * v) << 4) + lc];
+#pragma unroll
+                                for (int kc = 0; kc < 4; ++kc) { b1[u][kc] = S.V[4 * kc + lr][(jj << 4) + lc]; b2[u][kc] = V2[4 * kc + lr][(jj << 4) + lc]; }
+                            }
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                // pivot column of step a: the tile is W1_i itself, not an update of its old content
+                                if (col_a[u]) c[u] = w_dlayout(dA1, S.V, i);
+                                else {
+#pragma unroll
+                                    for (int kc = 0; kc < 4; ++kc) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(n1[kc], b1[u][kc], c[u], 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                                for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(n2[kc], b2[u][kc], c[u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                if (!on[u]) continue;
+                                KP T = A + tile_base(i, j0 + u);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[u][v];
+                            }
+                        }
+                    }
+                    W::sync();
+                    GP_T(8);
+                    kt += 2;
+                    k0 += 2 * GP_B;
+                    continue;
+                }
+            }
+            const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
+            GP_T0();
+            gather(S.V, kt, bs);
             if (W::lane() == 0) S.pivot_bad = 0;
             W::sync();
             GP_T(0);
-            // (2) wavefront 0: D^-1 of the identity-padded pivot block, Gauss-Jordan in registers
-            if (w == 0) {
-                const int a = l >> 2, c = l & 3;
-                double p[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int b = 4 * c + r;
-                    p[r] = (a < bs && b < bs) ? S.V[b][k0 + a] : ((a == b) ? 1.0 : 0.0);
-                }
-                bool bad = false;
-                gp_inv16_pivots<0>(p, a, c, bad, prod, ld);
-                bad_acc = bad_acc || bad;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S.P[a][4 * c + r] = -p[r];        // the sweep leaves -D^-1
-                if (bad && l == 0) S.pivot_bad = 1;
-            }
+            invert(S.V, S.P, k0, bs);
             W::sync();
             if (S.pivot_bad != 0) return false;
             GP_T(1);
@@ -251,11 +437,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
                     for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = -S.P[lr + 4 * v][lc];
                     continue;
                 }
-                // W_i' = D^-1 V_i'  ->  register v of lane l = W_i(row lc, k = 4 v + lr): the A operand of the updates
-                gp_v4f64 wt = {0, 0, 0, 0};
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc)
-                    wt = __builtin_amdgcn_mfma_f64_16x16x4f64(dA[kc], S.V[4 * kc + lr][(i << 4) + lc], wt, 0, 0, 0);
+                const gp_v4f64 wt = w_alayout(dA, S.V, i);
                 if (i > kt) {
                     KP T = A + tile_base(i, kt);                          // A(16 i + lc, k0 + k) <- W_i(lc, k)
 #pragma unroll
@@ -315,10 +497,11 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, GpLds<NP, W::NWAVES>& S, double& logd
             }
             W::sync();
             GP_T(8);
+            ++kt;
+            k0 += GP_B;
         }
         // log|K| = (sum of exponents) ln 2 + log(mantissa product), known to wavefront 0
         double tot = (w == 0) ? (ld * 0.6931471805599453 + log(prod)) : 0.0;
-        (void)bad_acc;
         logdet = W::bcast_from_first_wave(tot);
         return true;
     }
@@ -391,8 +574,8 @@ LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1,
 // One evaluation of f = -log-likelihood and its gradient at p (george GP.log_likelihood /
 // grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten (by -K^-1).  On a
 // failed factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
-template <class W, int NP, class KP>
-LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, KP K, double& f, double* g, bool need_grad) {
+template <class W, int NP, class KP, class LDS>
+LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, double* g, bool need_grad) {
     const int lane = W::lane();
     constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;
     constexpr int RG = W::LANES / G;
@@ -453,7 +636,7 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, GpLds<NP, W::NWAVES>& S, K
     GP_T(4);
     double logdet;
     g[0] = g[1] = g[2] = g[3] = 0.0;
-    if (!gp_sweep_inverse<W, NP, KP>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
+    if (!gp_sweep_inverse<W, NP, KP, LDS>(K, n, S, logdet)) { f = 1e25; W::sync(); return; }
     GP_T(5);      // (sweep total)
     // alpha = the swept augmented row ; r' K^-1 r = -A(n, n)
     double sa = 0;
@@ -544,8 +727,8 @@ LCFE_FN bool gp_row_valid(const ObjIn& in, int i) {
 // `K` points to packed-triangle storage for NP points (LDS or global scratch).
 // `ev(p, n, f, g, need_grad)` evaluates the objective (gp_eval with the matrix in LDS / global
 // scratch, or gp_eval_reg with the matrix in registers).
-template <class W, int NP, class Ev>
-LCFE_FN void gp_object(const ObjIn& L, GpLds<NP, W::NWAVES>& S, Ev&& gp_ev, int32_t* st) {
+template <class W, int NP, class Ev, class LDS>
+LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
     const int lane = W::lane();
     double* o = S.out;
     for (int k = lane; k < GP_NCOL; k += W::LANES) o[k] = qnan();

@@ -81,9 +81,9 @@ struct Bins {
 __device__ __forceinline__ int set_bin_of(int64_t n) {
     return (n <= 128) ? 0 : (n <= 256) ? 1 : (n <= 512) ? 2 : (n <= 1024) ? 3 : (n <= 2048) ? 4 : 6;
 }
-constexpr int kGpSmallNP = 240;     // matrix in global scratch, 16-wide pivot blocks, two 512-thread workgroups per CU
-constexpr int kGpMidNP = 512;       // matrix in global scratch, 16-wide pivot blocks, one 1024-thread workgroup per CU
-constexpr int kGpGlobalNP = 768;    // matrix in global scratch, 8-wide pivot blocks (512..767 rows)
+constexpr int kGpSmallNP = 240;     // matrix in global scratch, two pivot tiles per pass, two 512-thread workgroups per CU
+constexpr int kGpMidNP = 480;       // matrix in global scratch, two pivot tiles per pass, one 1024-thread workgroup per CU
+constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one pivot tile per pass (480..767 rows)
 // GP window on the ROW count of the object (>= its valid points); one row of the tile storage is the
 // augmented residual row, so the caps are NP - 1.
 __device__ __forceinline__ int gp_bin_of(int64_t n) {
@@ -275,7 +275,9 @@ constexpr size_t kGpSmallBytes = (size_t)kGpSmallGrid * gp_store_doubles(kGpSmal
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
-template <int NP> struct gp_threads { static constexpr int T = (NP >= 512) ? 1024 : ((NP >= 160) ? 512 : 256); };
+template <int NP> struct gp_threads { static constexpr int T = (NP >= 480) ? 1024 : ((NP >= 160) ? 512 : 256); };
+// the two global-scratch tiers whose second pivot panel fits LDS sweep two pivot tiles per pass over the matrix
+template <int NP, bool GLOBAL_K> struct gp_fuse { static constexpr bool F = GLOBAL_K && NP <= 480; };
 template <int NP> struct gp_grid_cap { static constexpr int G = (NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid; };
 
 // waves per SIMD to leave room for: the 64- and 112-row tiers fit two or more workgroups per CU in LDS,
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP>::N)) void gp_kerne
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch,
                                                  unsigned long long* ticket) {
     using W = BlockDev<gp_threads<NP>::T>;
-    __shared__ GpLds<NP, W::NWAVES> S;
+    __shared__ GpLds<NP, W::NWAVES, gp_fuse<NP, GLOBAL_K>::F> S;
     __shared__ double Klds[GLOBAL_K ? 1 : gp_store_doubles(NP)];
     __shared__ long long next_ticket;
     double* Kg = kscratch + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
