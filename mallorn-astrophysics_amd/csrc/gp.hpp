@@ -571,6 +571,15 @@ LCFE_FN double gp_kernel(double dt2, double dl2, double c, double m0, double m1,
     return c * (1.0 + u) * ex;
 }
 
+// Device tile passes: the same kernel with the two metric divisions replaced by multiplications with 1/M0, 1/M1
+// (computed once per evaluation) -- q0 = dt^2/M0 and q1 = dl^2/M1 are also what the gradient needs.
+LCFE_FN double gp_kernel_q(double q0, double q1, double c, double& e) {
+    const double u = sqrt(3.0 * (q0 + q1));
+    const double ex = exp(-u);
+    e = 1.5 * c * ex;
+    return c * (1.0 + u) * ex;
+}
+
 // One evaluation of f = -log-likelihood and its gradient at p (george GP.log_likelihood /
 // grad_log_likelihood as wrapped by multiband_gp.py:141-154).  K is overwritten (by -K^-1).  On a
 // failed factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
@@ -581,6 +590,8 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
     constexpr int RG = W::LANES / G;
     const int rl = lane / G, cl = lane % G;
     const double mu = p[0], c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
+    const double im0 = 1.0 / m0, im1 = 1.0 / m1;
+    (void)im0; (void)im1;
     GP_T0();
     // Gram matrix, tile-packed lower triangle
 #if defined(__HIPCC__)
@@ -609,7 +620,7 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
                     const int r = (i << 4) + lr + 4 * v;
                     const double dt = ti[v] - tj, dl = li[v] - lj;
                     double e;
-                    double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
+                    double k = gp_kernel_q(dt * dt * im0, dl * dl * im1, c, e);
                     if (r == cj) k += ni[v];
                     // rows / columns beyond the points: the augmented residual row, zeros elsewhere
                     if (r >= n || cj >= n) k = (r == n && cj < n) ? rj : 0.0;
@@ -680,13 +691,13 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
                     // masked out (its inputs may be stale memory)
                     const bool in = (r < n && cj <= r);
                     const double dt = in ? ti[v] - tj : 0.0, dl = in ? li[v] - lj : 0.0;
-                    const double dt2 = dt * dt, dl2 = dl * dl;
+                    const double q0 = dt * dt * im0, q1 = dl * dl * im1;
                     double e;
-                    const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
+                    const double k = gp_kernel_q(q0, q1, c, e);
                     const double a = in ? (ai[v] * aj + T[((lr + 4 * v) << 4) + lc]) * ((cj == r) ? 1.0 : 2.0) : 0.0;
                     g1 += a * k;
-                    g2 += a * e * dt2 / m0;
-                    g3 += a * e * dl2 / m1;
+                    g2 += a * e * q0;
+                    g3 += a * e * q1;
                 }
             }
         }
