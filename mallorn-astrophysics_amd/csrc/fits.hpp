@@ -66,16 +66,11 @@ LCFE_FN TrfView<5> bazin_view(BazinLds<CAP>& S, int band, int band_start) {
     return v;
 }
 
-// bazin_fitting.py:63-179 for one band's time-sorted rows -> out8 (wave-shared, lane 0 writes)
+// bazin_fitting.py:97-126: start point, bounds and weights of one band's fit (m >= 5 time-sorted rows)
 template <class W, class Store>
-LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double* e, int m,
-                                 Store& V, double* slot, unsigned long long* keys, double* out8) {
+LCFE_FN void bazin_prepare(const double* t, const double* f, const double* e, int m, Store& V, double* slot,
+                           unsigned long long* keys, TrfState<5>& Z) {
     const int lane = W::lane();
-    TrfResult res{TRF_FAIL_TOO_FEW, 0};
-    if (m < 5) {                                                   // :76-87
-        if (lane == 0) for (int k = 0; k < 8; ++k) out8[k] = qnan();
-        return res;
-    }
     const int pk = wave_argmax_first<W>(f, m);                     // :97  np.argmax on the sorted rows
     const double med = wave_median<W>(f, m, slot, keys);           // :99-100
     const double fpk = f[pk];
@@ -85,7 +80,7 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
     for (int i = lane; i < m; i += W::LANES) { mx = fmax(mx, f[i]); nanf = nanf || is_nan(f[i]); }
     mx = W::max(mx);
     if (W::any(nanf)) mx = qnan();
-    Vec<5> x, lb, ub;
+    Vec<5>& x = Z.x; Vec<5>& lb = Z.lb; Vec<5>& ub = Z.ub;
     x[0] = fpk - med; x[1] = t[pk]; x[2] = duration * 0.2; x[3] = duration * 0.3; x[4] = med;    // :132
     lb[0] = 0; lb[1] = t[0]; lb[2] = 0.1; lb[3] = 0.1; lb[4] = -mx;                                // :114-118
     ub[0] = 3 * mx; ub[1] = t[m - 1]; ub[2] = duration; ub[3] = duration; ub[4] = 2 * mx;
@@ -93,12 +88,19 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
         const double sg = (e[i] > 0) ? e[i] : 1.0;                 // :126
         V.w[i] = 1.0 / sg;                                         // _minpack_py.py:981 transform = 1/sigma
     }
+    Z.max_nfev = 2000;                                             // :136 maxfev
     W::sync();
-    res = trf_fit<W, BazinModel, Store>(BazinModel(), t, f, m, x, lb, ub, 2000, V);
-    if (res.status <= 0) {                                         // :168-179 any exception -> NaN
+}
+
+// bazin_fitting.py:139-179: clipping, reduced chi^2 and the derived columns of a finished fit -> out8
+template <class W>
+LCFE_FN void bazin_finish(const double* t, const double* f, const double* e, int m, const TrfState<5>& Z, double* out8) {
+    const int lane = W::lane();
+    if (Z.res.status <= 0) {                                       // :168-179 any exception -> NaN
         if (lane == 0) for (int k = 0; k < 8; ++k) out8[k] = qnan();
-        return res;
+        return;
     }
+    const Vec<5>& x = Z.x;
     Vec<5> q;
     q[0] = np_clip(x[0], -1e6, 1e6);                               // :142-145
     q[1] = x[1];
@@ -119,7 +121,42 @@ LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double*
         out8[6] = np_clip(q[2] / (q[3] + 1e-6), 0.0, 100.0);       // :154
         out8[7] = np_clip(q[0] + q[4], -1e6, 1e6);                 // :155
     }
-    return res;
+}
+
+// bazin_fitting.py:63-179 for one band's time-sorted rows -> out8 (wave-shared, lane 0 writes)
+template <class W, class Store>
+LCFE_FN TrfResult bazin_fit_band(const double* t, const double* f, const double* e, int m,
+                                 Store& V, double* slot, unsigned long long* keys, double* out8) {
+    const int lane = W::lane();
+    if (m < 5) {                                                   // :76-87
+        if (lane == 0) for (int k = 0; k < 8; ++k) out8[k] = qnan();
+        return TrfResult{TRF_FAIL_TOO_FEW, 0};
+    }
+    TrfState<5> Z;
+    bazin_prepare<W, Store>(t, f, e, m, V, slot, keys, Z);
+    trf_begin<W, BazinModel, Store>(BazinModel(), t, f, m, Z, V);
+    while (Z.phase != TRF_PH_DONE) {
+        if (Z.phase == TRF_PH_OUTER) trf_outer<W, BazinModel, Store>(m, Z, V);
+        else trf_inner<W, BazinModel, Store>(BazinModel(), t, f, m, Z, V);
+    }
+    bazin_finish<W>(t, f, e, m, Z, out8);
+    return Z.res;
+}
+
+// bazin_fitting.py:217-249: the four cross-band columns from the 48 per-band ones (scalar code)
+LCFE_FN void mean_std_small(const double* v, int n, double& mean, double& sd);
+LCFE_FN void bazin_cross_band(double* o) {
+    double v[6];
+    int n = 0;
+    double mean, sd;
+    for (int k = 1; k <= 3; ++k) if (!is_nan(o[8 * k + 2])) v[n++] = o[8 * k + 2];     // :217-225 g,r,i
+    if (n >= 2) { mean_std_small(v, n, mean, sd); o[48] = sd / mean; } else o[48] = qnan();
+    n = 0;
+    for (int k = 1; k <= 3; ++k) if (!is_nan(o[8 * k + 3])) v[n++] = o[8 * k + 3];
+    if (n >= 2) { mean_std_small(v, n, mean, sd); o[49] = sd / mean; } else o[49] = qnan();
+    n = 0;
+    for (int k = 0; k < 6; ++k) if (!is_nan(o[8 * k + 5])) v[n++] = o[8 * k + 5];       // :238-249
+    if (n > 0) { mean_std_small(v, n, mean, sd); o[50] = mean; o[51] = sd; } else { o[50] = qnan(); o[51] = qnan(); }
 }
 
 // np.std(v)/np.mean(v) style helpers over <= 6 values (lane-0 scalar code)
@@ -145,20 +182,7 @@ LCFE_FN void bazin_object(const ObjLds<CAP>& L, BazinLds<CAP>& S, int32_t* st) {
         W::sync();
     }
     WW::sync();
-    if (WW::lane() == 0) {
-        double* o = S.out;
-        double v[6];
-        int n = 0;
-        double mean, sd;
-        for (int k = 1; k <= 3; ++k) if (!is_nan(o[8 * k + 2])) v[n++] = o[8 * k + 2];     // :217-225 g,r,i
-        if (n >= 2) { mean_std_small(v, n, mean, sd); o[48] = sd / mean; } else o[48] = qnan();
-        n = 0;
-        for (int k = 1; k <= 3; ++k) if (!is_nan(o[8 * k + 3])) v[n++] = o[8 * k + 3];
-        if (n >= 2) { mean_std_small(v, n, mean, sd); o[49] = sd / mean; } else o[49] = qnan();
-        n = 0;
-        for (int k = 0; k < 6; ++k) if (!is_nan(o[8 * k + 5])) v[n++] = o[8 * k + 5];       // :238-249
-        if (n > 0) { mean_std_small(v, n, mean, sd); o[50] = mean; o[51] = sd; } else { o[50] = qnan(); o[51] = qnan(); }
-    }
+    if (WW::lane() == 0) bazin_cross_band(S.out);
     WW::sync();
 }
 

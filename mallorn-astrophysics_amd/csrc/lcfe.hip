@@ -70,8 +70,9 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 1;
+constexpr int kNumLists = 2 * kNumBins + 2;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
+constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -261,6 +262,170 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
     }
     LCFE_PT(5);
     LCFE_PT_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bazin fits, fit by fit.  With one object per wavefront the six band fits of a light curve run side by side in
+// 8-lane groups, but TRF's evaluation count is heavy-tailed (median 26, p99 556, cap 2000): the wave lasts as long as
+// its slowest band and the other groups idle -- 37 % of the lane-group time did useful work.  Here the unit of work is
+// ONE FIT: a partition pass writes every object's band-partitioned, time-sorted rows to global scratch and appends its
+// fits to a list per band-length tier; the fit kernel runs a flat loop in which every 8-lane group advances the solver
+// of its own fit by one phase per trip (trf.hpp: trf_outer / trf_inner) and takes the next fit from a device-side
+// ticket counter the moment its own is finished -- the groups of a wave never wait for each other.  The arithmetic of
+// a fit is exactly that of bazin_fit_band; only the schedule differs.
+constexpr int kFitTiers = 4;
+constexpr int kFitCaps[kFitTiers] = {32, 64, 128, 256};     // rows of one band
+constexpr int kFitCountBase = 32;                           // counts[32 + t]: length of fit list t
+constexpr int kFitTicketBase = 96;                          // tickets[96 + t]
+struct FitWs {
+    double* pt;            // band-partitioned copies of t / flux / err, indexed like the CSR arrays
+    double* pf;
+    double* pe;
+    int* pboff;            // [n_obj][8] band offsets inside the object's slice
+    int* fits;             // [kFitTiers][6 n_obj] fit ids (object * 8 + band)
+    int64_t fit_stride;
+};
+
+template <int BCAP>
+struct FitRegion {
+    double t[BCAP], f[BCAP];
+    double r[BCAP], rn[BCAP], w[BCAP];     // rn doubles as the key scratch of the median before the first trial point
+    double A[6][BCAP + 5];
+    double slot[2];
+};
+
+// partition pass: one object per wavefront (tier lists of the feature sets), up to `chunk` objects per ticket
+template <int CAP>
+__global__ __launch_bounds__(64, 2) void bazin_partition_kernel(BatchView B, Bins bins, int bin, int nan_from, FitWs F, double* out, int ld,
+                                                                int col0, int32_t* status, int st_ld, int st0,
+                                                                unsigned long long* ticket, int chunk) {
+    __shared__ ObjLds<CAP> L;
+    __shared__ long long next_ticket;
+    __shared__ int loc[kFitTiers][64], nloc[kFitTiers], base_of[kFitTiers];
+    using W = WaveDev;
+    const int count = bins.counts[bin];
+    const int* list = bins.lists + (int64_t)bin * bins.stride;
+    const int per_wave = count / (4 * (int)gridDim.x);
+    chunk = (per_wave < 1) ? 1 : ((per_wave < chunk) ? per_wave : chunk);
+    for (;;) {
+        if (threadIdx.x == 0) { next_ticket = (long long)atomicAdd(ticket, 1ull); for (int q = 0; q < kFitTiers; ++q) nloc[q] = 0; }
+        __syncthreads();
+        const int64_t base = next_ticket * chunk;
+        __syncthreads();
+        if (base >= count) break;
+        const int nk = (count - base < chunk) ? (int)(count - base) : chunk;
+        for (int k = 0; k < nk; ++k) {
+            const int64_t i = list[base + k];
+            const int64_t s = B.offsets[i];
+            const int n = (int)(B.offsets[i + 1] - s);
+            ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, n, qnan()};
+            stage_object<W, CAP>(in, L);
+            const int nb = L.boff[6];
+            for (int q = threadIdx.x; q < nb; q += 64) { F.pt[s + q] = L.bt[q]; F.pf[s + q] = L.bf[q]; F.pe[s + q] = L.be[q]; }
+            if (threadIdx.x < 8) F.pboff[i * 8 + threadIdx.x] = L.boff[threadIdx.x];
+            int mb = 0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) { const int m = L.boff[b + 1] - L.boff[b]; mb = (m > mb) ? m : mb; }
+            if (mb > kFitCaps[kFitTiers - 1]) {
+                // a band beyond the largest fit tier: the whole object goes to the object-level kernel
+                if (threadIdx.x == 0) {
+                    const int slot = atomicAdd(&bins.counts[kBazinFallbackList], 1);
+                    bins.lists[(int64_t)kBazinFallbackList * bins.stride + slot] = (int)i;
+                }
+            } else if (threadIdx.x < 6) {
+                const int b = threadIdx.x;
+                const int m = L.boff[b + 1] - L.boff[b];
+                if (m < 5) {                                                    // bazin_fitting.py:76-87
+                    double* o8 = out + i * (int64_t)ld + col0 + 8 * b;
+                    for (int q = 0; q < 8; ++q) o8[q] = qnan();
+                    if (status) { status[i * (int64_t)st_ld + st0 + 2 * b] = TRF_FAIL_TOO_FEW; status[i * (int64_t)st_ld + st0 + 2 * b + 1] = 0; }
+                } else {
+                    const int tier = (m <= kFitCaps[0]) ? 0 : ((m <= kFitCaps[1]) ? 1 : ((m <= kFitCaps[2]) ? 2 : 3));
+                    const int slot = atomicAdd(&nloc[tier], 1);                 // LDS atomic: order inside a chunk is free
+                    loc[tier][slot] = (int)i * 8 + b;
+                }
+            }
+            __syncthreads();
+        }
+        // one global atomic per tier and chunk
+        if (threadIdx.x < kFitTiers) base_of[threadIdx.x] = nloc[threadIdx.x] ? atomicAdd(&bins.counts[kFitCountBase + threadIdx.x], nloc[threadIdx.x]) : 0;
+        __syncthreads();
+        for (int tr = 0; tr < kFitTiers; ++tr)
+            for (int q = threadIdx.x; q < nloc[tr]; q += 64) F.fits[tr * F.fit_stride + base_of[tr] + q] = loc[tr][q];
+        __syncthreads();
+    }
+    nan_fill_bins<W>(bins, 0, nan_from, out, ld, col0, BAZIN_NCOL, status, st_ld, st0, 12);
+}
+
+enum { FIT_IDLE = 3, FIT_EXIT = 4 };      // beside TRF_PH_OUTER / INNER / DONE
+
+template <int BCAP> struct fit_waves { static constexpr int N = (BCAP <= 32) ? 2 : 1; };
+// lane groups of a wave that take fits: all eight while their LDS regions fit next to each other, six in the 256-row tier
+template <int BCAP> struct fit_groups { static constexpr int N = (BCAP <= 128) ? 8 : 6; };
+
+template <int BCAP>
+__global__ __launch_bounds__(64, (fit_waves<BCAP>::N)) void bazin_fit_kernel(BatchView B, Bins bins, FitWs F, int tier, double* out, int ld, int col0,
+                                                            int32_t* status, int st_ld, int st0, unsigned long long* ticket) {
+    using G = GroupDev<8>;
+    constexpr int NG = fit_groups<BCAP>::N;
+    __shared__ FitRegion<BCAP> R[NG];
+    FitRegion<BCAP>& Rg = R[(G::group_id() < NG) ? G::group_id() : 0];
+    TrfView<5> V;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) V.A[k] = Rg.A[k];
+    V.r = Rg.r; V.rn = Rg.rn; V.w = Rg.w;
+    const int count = bins.counts[kFitCountBase + tier];
+    const int* list = F.fits + (int64_t)tier * F.fit_stride;
+    const int gl = G::lane();
+    const int leader = (int)(threadIdx.x & 63) & ~7;
+    TrfState<5> Z;
+    Z.phase = (G::group_id() < NG) ? FIT_IDLE : FIT_EXIT;
+    int m = 0;
+    int64_t obj = 0, src = 0;
+    int band = 0;
+    for (;;) {
+        if (Z.phase == FIT_IDLE) {
+            int tk = 0;
+            if (gl == 0) tk = (int)atomicAdd(ticket, 1ull);
+            tk = __shfl(tk, leader, 64);
+            if (tk >= count) Z.phase = FIT_EXIT;
+            else {
+                const int id = list[tk];
+                obj = id >> 3;
+                band = id & 7;
+                const int b0 = F.pboff[obj * 8 + band];
+                m = F.pboff[obj * 8 + band + 1] - b0;
+                src = B.offsets[obj] + b0;
+                for (int i = gl; i < m; i += 8) { Rg.t[i] = F.pt[src + i]; Rg.f[i] = F.pf[src + i]; }
+                G::sync();
+                bazin_prepare<G, TrfView<5>>(Rg.t, Rg.f, F.pe + src, m, V, Rg.slot, reinterpret_cast<unsigned long long*>(Rg.rn), Z);
+                trf_begin<G, BazinModel, TrfView<5>>(BazinModel(), Rg.t, Rg.f, m, Z, V);
+            }
+        }
+        if (__ballot(Z.phase != FIT_EXIT) == 0ull) break;
+        if (Z.phase == TRF_PH_OUTER) trf_outer<G, BazinModel, TrfView<5>>(m, Z, V);
+        if (Z.phase == TRF_PH_INNER) trf_inner<G, BazinModel, TrfView<5>>(BazinModel(), Rg.t, Rg.f, m, Z, V);
+        if (Z.phase == TRF_PH_DONE) {
+            bazin_finish<G>(Rg.t, Rg.f, F.pe + src, m, Z, out + obj * (int64_t)ld + col0 + 8 * band);
+            if (status && gl == 0) {
+                status[obj * (int64_t)st_ld + st0 + 2 * band] = Z.res.status;
+                status[obj * (int64_t)st_ld + st0 + 2 * band + 1] = Z.res.nfev;
+            }
+            G::sync();
+            Z.phase = FIT_IDLE;
+        }
+    }
+}
+
+// the four cross-band columns of every object (bazin_fitting.py:217-249) once all its fits are in
+__global__ __launch_bounds__(256) void bazin_cross_kernel(BatchView B, double* out, int ld, int col0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.n_obj) return;
+    double o[BAZIN_NCOL];
+    double* row = out + i * (int64_t)ld + col0;
+    for (int k = 0; k < 48; ++k) o[k] = row[k];
+    bazin_cross_band(o);
+    for (int k = 48; k < 52; ++k) row[k] = o[k];
 }
 
 int num_cus(int dev);
@@ -609,6 +774,88 @@ int launch_set(const BatchView& B, const Bins& bins, int64_t max_len, double* ou
     return 0;
 }
 
+size_t bazin_ws_bytes(int64_t n_obj, int64_t n_points) {
+    const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)(n_obj > 0 ? n_obj : 1);
+    return ((3 * 8 * np + 255) & ~(size_t)255) + ((32 * no + 255) & ~(size_t)255) + ((4 * (size_t)kFitTiers * 6 * no + 255) & ~(size_t)255);
+}
+
+template <int CAP>
+int launch_bazin_partition(const BatchView& B, const Bins& bins, int bin, int nan_from, const FitWs& F, double* out, int ld, int col0,
+                           int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bazin_partition_kernel<CAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((bazin_partition_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, nan_from, F, out, ld, col0,
+                       status, st_ld, st0, ticket, 8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int BCAP>
+int launch_bazin_fits(const BatchView& B, const Bins& bins, const FitWs& F, int tier, double* out, int ld, int col0, int32_t* status,
+                      int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bazin_fit_kernel<BCAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid * 8 > 6 * B.n_obj) grid = (6 * B.n_obj + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((bazin_fit_kernel<BCAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, F, tier, out, ld, col0, status,
+                       st_ld, st0, ticket);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Bazin: partition pass per object tier, the fit kernel per band-length tier (longest first), the object-level
+// kernel for objects with a band beyond the largest fit tier, then the cross-band columns.
+int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
+                 int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, void* ws, size_t ws_bytes,
+                 int64_t n_points) {
+    if (!ws || ws_bytes < bazin_ws_bytes(B.n_obj, n_points))
+        return fail_msg("lcfe_extract_device: workspace too small for the Bazin fit lists");
+    const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)B.n_obj;
+    FitWs F;
+    char* p = (char*)ws;
+    F.pt = (double*)p; F.pf = F.pt + np; F.pe = F.pf + np;
+    p += (3 * 8 * np + 255) & ~(size_t)255;
+    F.pboff = (int*)p;
+    p += (32 * no + 255) & ~(size_t)255;
+    F.fits = (int*)p;
+    F.fit_stride = 6 * (int64_t)no;
+    int last = 0;
+    while (last < 3 && kTiers[last] < max_len) ++last;
+    unsigned long long* tk = tickets + SET_BAZIN * 8;
+    for (int ti = 0; ti <= last; ++ti) {
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_bazin_partition<128>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 1: rc = launch_bazin_partition<256>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 2: rc = launch_bazin_partition<512>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 3: rc = launch_bazin_partition<1024>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+    }
+    int rc = launch_bazin_fits<256>(B, bins, F, 3, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 3);
+    if (!rc) rc = launch_bazin_fits<128>(B, bins, F, 2, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 2);
+    if (!rc) rc = launch_bazin_fits<64>(B, bins, F, 1, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 1);
+    if (!rc) rc = launch_bazin_fits<32>(B, bins, F, 0, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 0);
+    if (rc) return rc;
+    *n_launch += 4;
+    // objects with a band of more than 256 rows: the object-level kernel (all 52 columns)
+    rc = launch_tier<SET_BAZIN, 1024>(B, bins, kBazinFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5);
+    if (rc) return rc;
+    ++*n_launch;
+    hipLaunchKernelGGL(bazin_cross_kernel, dim3((unsigned)((B.n_obj + 255) / 256)), dim3(256), 0, stream, B, out, ld, col0);
+    HIP_TRY(hipGetLastError());
+    ++*n_launch;
+    return 0;
+}
+
 template <int CAP>
 int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
                      int dev, unsigned long long* ticket) {
@@ -761,9 +1008,10 @@ constexpr size_t kWsHeader = 2048;
 static size_t list_bytes(int64_t n_obj) {
     return (((size_t)(n_obj > 0 ? n_obj : 0) * kNumLists * sizeof(int)) + 255) & ~(size_t)255;
 }
-size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t) {
+size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points) {
     size_t b = kWsHeader + list_bytes(n_obj);
     if (mask & (1 << SET_GP2D)) b += kGpSmallBytes + kGpMidBytes + kGpGlobalBytes;
+    if (mask & (1 << SET_BAZIN)) b += bazin_ws_bytes(n_obj, n_points);
     return b;
 }
 
@@ -800,8 +1048,15 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     unsigned long long* tickets = (unsigned long long*)d_workspace;
     int* counts = (int*)((char*)d_workspace + 1024);
     int* lists = (int*)((char*)d_workspace + kWsHeader);
-    double* gp_scratch = (workspace_bytes > kWsHeader + lists_b) ? (double*)((char*)d_workspace + kWsHeader + lists_b) : nullptr;
-    const size_t gp_scratch_bytes = gp_scratch ? workspace_bytes - kWsHeader - lists_b : 0;
+    if (workspace_bytes < lcfe_workspace_bytes(mask, n_obj, n_points))
+        return fail_msg("lcfe_extract_device: workspace smaller than lcfe_workspace_bytes(mask, n_obj, n_points)");
+    // after the lists: the GP scratch slabs (if the 2-D GP is in the mask), then the Bazin fit workspace
+    char* region = (char*)d_workspace + kWsHeader + lists_b;
+    const size_t gp_scratch_bytes = (mask & (1 << SET_GP2D)) ? kGpSmallBytes + kGpMidBytes + kGpGlobalBytes : 0;
+    double* gp_scratch = gp_scratch_bytes ? (double*)region : nullptr;
+    region += gp_scratch_bytes;
+    void* bazin_ws = (mask & (1 << SET_BAZIN)) ? (void*)region : nullptr;
+    const size_t bazin_bytes = bazin_ws ? bazin_ws_bytes(n_obj, n_points) : 0;
     const Bins bins{lists, counts, n_obj};
     // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
     // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
@@ -868,7 +1123,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         int nl = 0, rc = 0;
         switch (s) {
             case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets); break;
-            case SET_BAZIN: rc = launch_set<SET_BAZIN>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_BAZIN: rc = launch_bazin(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, bazin_ws, bazin_bytes, n_points); break;
             case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;

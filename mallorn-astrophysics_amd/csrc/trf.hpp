@@ -438,267 +438,328 @@ struct TrfView {
     double* w;
 };
 
+// ---- the solver as a resumable machine.  One fit is a TrfState plus its Store; trf_begin runs the prologue, then
+// trf_outer (scaling, termination tests, QR + SVD of the augmented Jacobian) and trf_inner (ONE trial step; on the
+// end of scipy's inner loop also the acceptance and the new Jacobian) alternate until phase == TRF_PH_DONE.  The
+// arithmetic and its order are those of the monolithic loop this replaces; what changes is that a caller can
+// interleave the phases of several fits in one flat loop (lcfe.hip: the fit kernels keep every lane group busy by
+// handing a finished group its next fit while its neighbours iterate on).
+enum { TRF_PH_OUTER = 0, TRF_PH_INNER = 1, TRF_PH_DONE = 2 };
+
+template <int N>
+struct TrfState {
+    Vec<N> x, lb, ub, g, v, dv, d, diag_h, g_h, x_new;
+    TriFactor<N> T;
+    double sv[N], Vm[N][N], uf[N];
+    double cost, cost_new, Delta, alpha, theta, actual;
+    int status;                // -99 while running (scipy's None)
+    int phase;
+    int max_nfev;
+    TrfResult res;
+};
+
+template <class W, class Model, class Store>
+LCFE_FN void trf_residual(const Model& model, const double* t, const double* y, int m, Store& S, const Vec<Model::NP>& xx,
+                          double* out, double& cost2, bool& finite) {
+    double c = 0;
+    bool ok = true;
+    for (int i = W::lane(); i < m; i += W::LANES) {
+        const double v = S.w[i] * (model(t[i], xx) - y[i]);
+        out[i] = v;
+        ok = ok && finite_d(v);
+        c += v * v;
+    }
+    cost2 = W::sum(c);
+    finite = W::all(ok);
+}
+
+// FD Jacobian into S.A columns (unscaled), returns g = J^T f and a finiteness flag
+template <class W, class Model, class Store>
+LCFE_FN void trf_jacobian(const Model& model, const double* t, const double* y, int m, Store& S, const Vec<Model::NP>& xx,
+                          const Vec<Model::NP>& lb, const Vec<Model::NP>& ub, Vec<Model::NP>& g, bool& finite) {
+    constexpr int N = Model::NP;
+    const int lane = W::lane();
+    bool ok = true;
+    double gacc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        // _numdiff.py:146-179 absolute step; :13-64 one-sided bound adjustment
+        double h = TRF_SQRT_EPS * ((xx[k] >= 0) ? 1.0 : -1.0) * fmax(1.0, fabs(xx[k]));
+        const double lower = xx[k] - lb[k], upper = ub[k] - xx[k];
+        const double xt = xx[k] + h;
+        const bool violated = (xt < lb[k]) || (xt > ub[k]);
+        const bool fitting = fabs(h) <= fmax(lower, upper);
+        if (violated && fitting) h = -h;
+        if (!fitting) h = (upper >= lower) ? upper : -lower;
+        Vec<N> x1 = xx;
+        x1[k] = xx[k] + h;
+        const double dx = x1[k] - xx[k];
+        double ga = 0;
+        for (int i = lane; i < m; i += W::LANES) {
+            const double f1 = S.w[i] * (model(t[i], x1) - y[i]);
+            const double jv = (f1 - S.r[i]) / dx;
+            S.A[k][i] = jv;
+            ok = ok && finite_d(jv);
+            ga += jv * S.r[i];
+        }
+        gacc[k] = ga;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) g[k] = W::sum(gacc[k]);
+    finite = W::all(ok);
+}
+
+// CL scaling  (common.py:467-508); all bounds here are finite
+template <int N>
+LCFE_FN void trf_cl_scaling(TrfState<N>& Z) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        Z.v[i] = 1.0; Z.dv[i] = 0.0;
+        if (Z.g[i] < 0 && finite_d(Z.ub[i])) { Z.v[i] = Z.ub[i] - Z.x[i]; Z.dv[i] = -1.0; }
+        if (Z.g[i] > 0 && finite_d(Z.lb[i])) { Z.v[i] = Z.x[i] - Z.lb[i]; Z.dv[i] = 1.0; }
+    }
+}
+
+// prologue of curve_fit / least_squares + first residual and Jacobian.  Z.x, Z.lb, Z.ub, Z.max_nfev set by the caller.
+template <class W, class Model, class Store>
+LCFE_FN void trf_begin(const Model& model, const double* t, const double* y, int m, TrfState<Model::NP>& Z, Store& S) {
+    constexpr int N = Model::NP;
+    const int lane = W::lane();
+    Z.res = TrfResult{TRF_FAIL_MAXFEV, 0};
+    Z.phase = TRF_PH_DONE;
+    bool data_ok = true;
+    for (int i = lane; i < m; i += W::LANES) data_ok = data_ok && finite_d(t[i]) && finite_d(y[i]);
+    if (!W::all(data_ok)) { Z.res.status = TRF_FAIL_NONFINITE; return; }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (!(Z.lb[i] < Z.ub[i])) { Z.res.status = TRF_FAIL_BOUNDS; return; }     // also catches NaN bounds
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (!(Z.x[i] >= Z.lb[i] && Z.x[i] <= Z.ub[i])) { Z.res.status = TRF_FAIL_X0; return; }
+    make_strictly_feasible(Z.x, Z.lb, Z.ub, 1e-10);
+    double cost2;
+    bool fin;
+    trf_residual<W, Model, Store>(model, t, y, m, S, Z.x, S.r, cost2, fin);
+    Z.res.nfev = 1;
+    if (!fin) { Z.res.status = TRF_FAIL_NONFINITE; return; }
+    Z.cost = 0.5 * cost2;
+    W::sync();
+    trf_jacobian<W, Model, Store>(model, t, y, m, S, Z.x, Z.lb, Z.ub, Z.g, fin);
+    if (!fin) { Z.res.status = TRF_FAIL_NONFINITE; return; }
+    trf_cl_scaling<N>(Z);
+    {
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const double q = Z.x[i] / sqrt(Z.v[i]); s += q * q; }
+        Z.Delta = sqrt(s);                                 // trf.py:232-236 (x0 * scale_inv / v**0.5)
+        if (Z.Delta == 0) Z.Delta = 1.0;
+    }
+    Z.alpha = 0.0;
+    Z.status = -99;
+    Z.phase = TRF_PH_OUTER;
+}
+
+// top of scipy's outer loop up to the SVD; ends the fit when a termination test fires
+template <class W, class Model, class Store>
+LCFE_FN void trf_outer(int m, TrfState<Model::NP>& Z, Store& S) {
+    constexpr int N = Model::NP;
+    const int lane = W::lane();
+    const int M = m + N;
+    const double gtol = 1e-8;
+    TRF_T0();
+    trf_cl_scaling<N>(Z);
+    double g_norm = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) g_norm = fmax(g_norm, fabs(Z.g[i] * Z.v[i]));
+    if (g_norm < gtol) Z.status = 1;
+#ifdef LCFE_TRF_TRACE
+    printf("it nfev=%d cost=%.17g Delta=%.17g g_norm=%.6e x=", Z.res.nfev, Z.cost, Z.Delta, g_norm);
+    for (int i = 0; i < N; ++i) printf("%.17g ", Z.x[i]);
+    printf("\n");
+#endif
+    if (Z.status != -99 || Z.res.nfev == Z.max_nfev) {
+        Z.res.status = (Z.status == -99) ? TRF_FAIL_MAXFEV : Z.status;
+        Z.phase = TRF_PH_DONE;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        Z.d[i] = sqrt(Z.v[i]);
+        Z.diag_h[i] = Z.g[i] * Z.dv[i];
+        Z.g_h[i] = Z.d[i] * Z.g[i];
+    }
+    // ---- augmented matrix in LDS: scale J columns by d, append diag rows and residual column
+    W::sync();
+    for (int i = lane; i < M; i += W::LANES) {
+        if (i < m) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) S.A[k][i] *= Z.d[k];
+            S.A[N][i] = S.r[i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) S.A[k][i] = (i - m == k) ? sqrt(Z.diag_h[k]) : 0.0;
+            S.A[N][i] = 0.0;
+        }
+    }
+    W::sync();
+    TRF_T(0);
+    // ---- Householder QR (in place); R and Q^T f end in rows 0..N-1
+    Vec<N> qtf;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        // norm of column k below (and including) row k, and its pivot element
+        double nn = 0;
+        for (int i = lane; i < M; i += W::LANES)
+            if (i >= k) { const double a = S.A[k][i]; nn += a * a; }
+        nn = W::sum(nn);
+        const double akk = S.A[k][k];
+        const double nrm = sqrt(nn);
+        const double alpha_h = (akk > 0) ? -nrm : nrm;
+        const double vk = akk - alpha_h;                 // v = x - alpha e_k
+        const double vtv = nn - 2.0 * alpha_h * akk + alpha_h * alpha_h;
+        // dot products of v with the remaining columns (and the residual column)
+        double dots[N + 1];
+#pragma unroll
+        for (int j = 0; j <= N; ++j) dots[j] = 0;
+        if (vtv > 0) {
+            for (int i = lane; i < M; i += W::LANES) {
+                if (i < k) continue;
+                const double vi = (i == k) ? vk : S.A[k][i];
+#pragma unroll
+                for (int j = 0; j <= N; ++j)
+                    if (j > k) dots[j] += vi * S.A[j][i];
+            }
+#pragma unroll
+            for (int j = 0; j <= N; ++j)
+                if (j > k) dots[j] = W::sum(dots[j]);
+            W::sync();
+            for (int i = lane; i < M; i += W::LANES) {
+                if (i < k) continue;
+                const double vi = (i == k) ? vk : S.A[k][i];
+#pragma unroll
+                for (int j = 0; j <= N; ++j)
+                    if (j > k) S.A[j][i] -= (2.0 * dots[j] / vtv) * vi;
+            }
+        }
+        W::sync();
+        Z.T.R[k][k] = (vtv > 0) ? alpha_h : akk;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j > k) Z.T.R[k][j] = S.A[j][k];
+        qtf[k] = S.A[N][k];
+        W::sync();
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j < i) Z.T.R[i][j] = 0.0;
+    TRF_T(1);
+    jacobi_svd<N>(Z.T, qtf, Z.sv, Z.Vm, Z.uf);
+    TRF_T(2);
+#ifdef LCFE_TRF_TRACE
+    printf("   sv="); for (int i = 0; i < N; ++i) printf("%.17g ", Z.sv[i]);
+    printf(" uf="); for (int i = 0; i < N; ++i) printf("%.17g ", Z.uf[i]);
+    printf(" qtf="); for (int i = 0; i < N; ++i) printf("%.17g ", qtf[i]);
+    printf("\n   R="); for (int i = 0; i < N; ++i) for (int j = i; j < N; ++j) printf("%.17g ", Z.T.R[i][j]);
+    printf("\n");
+#endif
+    Z.theta = fmax(0.995, 1 - g_norm);
+    Z.actual = -1.0;
+    Z.cost_new = Z.cost;
+    Z.phase = TRF_PH_INNER;
+}
+
+// one pass of scipy's inner loop (one trial point); when that loop ends, the acceptance step and the new Jacobian
+template <class W, class Model, class Store>
+LCFE_FN void trf_inner(const Model& model, const double* t, const double* y, int m, TrfState<Model::NP>& Z, Store& S) {
+    constexpr int N = Model::NP;
+    const int lane = W::lane();
+    const double ftol = 1e-8, xtol = 1e-8;
+    TRF_T0();
+    bool loop_ends = false;
+    {
+        Vec<N> p_h, p, step, step_h;
+        solve_lsq_trust_region<N>(m, Z.uf, Z.sv, Z.Vm, Z.Delta, Z.alpha, p_h);
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = Z.d[i] * p_h[i];
+        double predicted;
+        TRF_T(3);
+        if (!select_step<N>(Z.x, Z.T, Z.g_h, p, p_h, Z.d, Z.Delta, Z.lb, Z.ub, Z.theta, step, step_h, predicted)) {
+            Z.res.status = TRF_FAIL_GEOMETRY;
+            Z.phase = TRF_PH_DONE;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) Z.x_new[i] = Z.x[i] + step[i];
+        make_strictly_feasible(Z.x_new, Z.lb, Z.ub, 0.0);
+        TRF_T(4);
+        double c2;
+        bool f_ok;
+        trf_residual<W, Model, Store>(model, t, y, m, S, Z.x_new, S.rn, c2, f_ok);
+        Z.res.nfev += 1;
+        TRF_T(5);
+        const double step_h_norm = vnorm(step_h);
+        if (!f_ok) Z.Delta = 0.25 * step_h_norm;
+        else {
+            Z.cost_new = 0.5 * c2;
+            Z.actual = Z.cost - Z.cost_new;
+            // update_tr_radius (common.py:222-248)
+            double ratio;
+            if (predicted > 0) ratio = Z.actual / predicted;
+            else if (predicted == 0 && Z.actual == 0) ratio = 1;
+            else ratio = 0;
+            double Delta_new = Z.Delta;
+            if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
+            else if (ratio > 0.75 && step_h_norm > 0.95 * Z.Delta) Delta_new = Z.Delta * 2.0;
+            // check_termination (common.py:705-717)
+            const double step_norm = vnorm(step), x_norm = vnorm(Z.x);
+            const bool ftol_ok = (Z.actual < ftol * Z.cost) && (ratio > 0.25);
+            const bool xtol_ok = step_norm < xtol * (xtol + x_norm);
+            if (ftol_ok && xtol_ok) Z.status = 4;
+            else if (ftol_ok) Z.status = 2;
+            else if (xtol_ok) Z.status = 3;
+            if (Z.status != -99) loop_ends = true;
+            else {
+                Z.alpha *= Z.Delta / Delta_new;
+                Z.Delta = Delta_new;
+            }
+        }
+    }
+    // scipy: while actual_reduction <= 0 and nfev < max_nfev
+    if (!loop_ends && Z.actual <= 0 && Z.res.nfev < Z.max_nfev) return;       // another trial (phase stays INNER)
+    if (Z.actual > 0) {
+        Z.x = Z.x_new;
+        W::sync();
+        for (int i = lane; i < m; i += W::LANES) S.r[i] = S.rn[i];
+        Z.cost = Z.cost_new;
+        W::sync();
+        // scipy recomputes J here even when terminating; curve_fit then takes an SVD of it
+        // (check_finite) -> a non-finite final Jacobian is a failure too.
+        TRF_T(6);
+        bool fin;
+        trf_jacobian<W, Model, Store>(model, t, y, m, S, Z.x, Z.lb, Z.ub, Z.g, fin);
+        TRF_T(7);
+        if (!fin) { Z.res.status = TRF_FAIL_NONFINITE; Z.phase = TRF_PH_DONE; return; }
+    }
+    Z.phase = TRF_PH_OUTER;
+}
+
+// The fit in one call: r_i(x) = w_i*(model(t_i;x) - y_i), i < m.  t, y are wave-shared arrays (LDS); S.w must hold
+// the weights.  x holds p0 on entry and the solution on exit (wave-uniform).
 template <class W, class Model, class Store>
 LCFE_FN TrfResult trf_fit(const Model& model, const double* t, const double* y, int m,
                           Vec<Model::NP>& x, const Vec<Model::NP>& lb, const Vec<Model::NP>& ub, int max_nfev,
                           Store& S) {
-    constexpr int N = Model::NP;
-    const int lane = W::lane();
-    const int M = m + N;
-    TrfResult res{TRF_FAIL_MAXFEV, 0};
-    // ---- curve_fit / least_squares prologue
-    bool data_ok = true;
-    for (int i = lane; i < m; i += W::LANES) data_ok = data_ok && finite_d(t[i]) && finite_d(y[i]);
-    if (!W::all(data_ok)) { res.status = TRF_FAIL_NONFINITE; return res; }
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        if (!(lb[i] < ub[i])) { res.status = TRF_FAIL_BOUNDS; return res; }     // also catches NaN bounds
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        if (!(x[i] >= lb[i] && x[i] <= ub[i])) { res.status = TRF_FAIL_X0; return res; }
-    make_strictly_feasible(x, lb, ub, 1e-10);
-
-    auto residual = [&](const Vec<N>& xx, double* out, double& cost2, bool& finite) {
-        double c = 0;
-        bool ok = true;
-        for (int i = lane; i < m; i += W::LANES) {
-            const double v = S.w[i] * (model(t[i], xx) - y[i]);
-            out[i] = v;
-            ok = ok && finite_d(v);
-            c += v * v;
-        }
-        cost2 = W::sum(c);
-        finite = W::all(ok);
-    };
-    // FD Jacobian into S.A columns (unscaled), returns g = J^T f and a finiteness flag
-    auto jacobian = [&](const Vec<N>& xx, Vec<N>& g, bool& finite) {
-        bool ok = true;
-        double gacc[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            // _numdiff.py:146-179 absolute step; :13-64 one-sided bound adjustment
-            double h = TRF_SQRT_EPS * ((xx[k] >= 0) ? 1.0 : -1.0) * fmax(1.0, fabs(xx[k]));
-            const double lower = xx[k] - lb[k], upper = ub[k] - xx[k];
-            const double xt = xx[k] + h;
-            const bool violated = (xt < lb[k]) || (xt > ub[k]);
-            const bool fitting = fabs(h) <= fmax(lower, upper);
-            if (violated && fitting) h = -h;
-            if (!fitting) h = (upper >= lower) ? upper : -lower;
-            Vec<N> x1 = xx;
-            x1[k] = xx[k] + h;
-            const double dx = x1[k] - xx[k];
-            double ga = 0;
-            for (int i = lane; i < m; i += W::LANES) {
-                const double f1 = S.w[i] * (model(t[i], x1) - y[i]);
-                const double jv = (f1 - S.r[i]) / dx;
-                S.A[k][i] = jv;
-                ok = ok && finite_d(jv);
-                ga += jv * S.r[i];
-            }
-            gacc[k] = ga;
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k) g[k] = W::sum(gacc[k]);
-        finite = W::all(ok);
-    };
-
-    double cost2;
-    bool fin;
-    residual(x, S.r, cost2, fin);
-    res.nfev = 1;
-    if (!fin) { res.status = TRF_FAIL_NONFINITE; return res; }
-    double cost = 0.5 * cost2;
-    Vec<N> g;
-    W::sync();
-    jacobian(x, g, fin);
-    if (!fin) { res.status = TRF_FAIL_NONFINITE; return res; }
-
-    // CL scaling  (common.py:467-508); all bounds here are finite
-    Vec<N> v, dv;
-    auto cl_scaling = [&]() {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            v[i] = 1.0; dv[i] = 0.0;
-            if (g[i] < 0 && finite_d(ub[i])) { v[i] = ub[i] - x[i]; dv[i] = -1.0; }
-            if (g[i] > 0 && finite_d(lb[i])) { v[i] = x[i] - lb[i]; dv[i] = 1.0; }
-        }
-    };
-    cl_scaling();
-    double Delta;
-    {
-        double s = 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) { const double q = x[i] / sqrt(v[i]); s += q * q; }
-        Delta = sqrt(s);                                   // trf.py:232-236 (x0 * scale_inv / v**0.5)
-        if (Delta == 0) Delta = 1.0;
+    TrfState<Model::NP> Z;
+    Z.x = x; Z.lb = lb; Z.ub = ub; Z.max_nfev = max_nfev;
+    trf_begin<W, Model, Store>(model, t, y, m, Z, S);
+    while (Z.phase != TRF_PH_DONE) {
+        if (Z.phase == TRF_PH_OUTER) trf_outer<W, Model, Store>(m, Z, S);
+        else trf_inner<W, Model, Store>(model, t, y, m, Z, S);
     }
-    double alpha = 0.0;
-    int status = -99;          // None
-    const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
-
-    while (true) {
-        TRF_T0();
-        cl_scaling();
-        double g_norm = 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) g_norm = fmax(g_norm, fabs(g[i] * v[i]));
-        if (g_norm < gtol) status = 1;
-#ifdef LCFE_TRF_TRACE
-        printf("it nfev=%d cost=%.17g Delta=%.17g g_norm=%.6e x=", res.nfev, cost, Delta, g_norm);
-        for (int i = 0; i < N; ++i) printf("%.17g ", x[i]);
-        printf("\n");
-#endif
-        if (status != -99 || res.nfev == max_nfev) break;
-
-        Vec<N> d, diag_h, g_h;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            d[i] = sqrt(v[i]);
-            diag_h[i] = g[i] * dv[i];
-            g_h[i] = d[i] * g[i];
-        }
-        // ---- augmented matrix in LDS: scale J columns by d, append diag rows and residual column
-        W::sync();
-        for (int i = lane; i < M; i += W::LANES) {
-            if (i < m) {
-#pragma unroll
-                for (int k = 0; k < N; ++k) S.A[k][i] *= d[k];
-                S.A[N][i] = S.r[i];
-            } else {
-#pragma unroll
-                for (int k = 0; k < N; ++k) S.A[k][i] = (i - m == k) ? sqrt(diag_h[k]) : 0.0;
-                S.A[N][i] = 0.0;
-            }
-        }
-        W::sync();
-        TRF_T(0);
-        // ---- Householder QR (in place); R and Q^T f end in rows 0..N-1
-        TriFactor<N> T;
-        Vec<N> qtf;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            // norm of column k below (and including) row k, and its pivot element
-            double nn = 0;
-            for (int i = lane; i < M; i += W::LANES)
-                if (i >= k) { const double a = S.A[k][i]; nn += a * a; }
-            nn = W::sum(nn);
-            const double akk = S.A[k][k];
-            const double nrm = sqrt(nn);
-            const double alpha_h = (akk > 0) ? -nrm : nrm;
-            const double vk = akk - alpha_h;                 // v = x - alpha e_k
-            const double vtv = nn - 2.0 * alpha_h * akk + alpha_h * alpha_h;
-            // dot products of v with the remaining columns (and the residual column)
-            double dots[N + 1];
-#pragma unroll
-            for (int j = 0; j <= N; ++j) dots[j] = 0;
-            if (vtv > 0) {
-                for (int i = lane; i < M; i += W::LANES) {
-                    if (i < k) continue;
-                    const double vi = (i == k) ? vk : S.A[k][i];
-#pragma unroll
-                    for (int j = 0; j <= N; ++j)
-                        if (j > k) dots[j] += vi * S.A[j][i];
-                }
-#pragma unroll
-                for (int j = 0; j <= N; ++j)
-                    if (j > k) dots[j] = W::sum(dots[j]);
-                W::sync();
-                for (int i = lane; i < M; i += W::LANES) {
-                    if (i < k) continue;
-                    const double vi = (i == k) ? vk : S.A[k][i];
-#pragma unroll
-                    for (int j = 0; j <= N; ++j)
-                        if (j > k) S.A[j][i] -= (2.0 * dots[j] / vtv) * vi;
-                }
-            }
-            W::sync();
-            T.R[k][k] = (vtv > 0) ? alpha_h : akk;
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (j > k) T.R[k][j] = S.A[j][k];
-            qtf[k] = S.A[N][k];
-            W::sync();
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (j < i) T.R[i][j] = 0.0;
-        TRF_T(1);
-        double sv[N], Vm[N][N], uf[N];
-        jacobi_svd<N>(T, qtf, sv, Vm, uf);
-        TRF_T(2);
-#ifdef LCFE_TRF_TRACE
-        printf("   sv="); for (int i = 0; i < N; ++i) printf("%.17g ", sv[i]);
-        printf(" uf="); for (int i = 0; i < N; ++i) printf("%.17g ", uf[i]);
-        printf(" qtf="); for (int i = 0; i < N; ++i) printf("%.17g ", qtf[i]);
-        printf("\n   R="); for (int i = 0; i < N; ++i) for (int j = i; j < N; ++j) printf("%.17g ", T.R[i][j]);
-        printf("\n");
-#endif
-
-        const double theta = fmax(0.995, 1 - g_norm);
-        double actual = -1.0;
-        Vec<N> x_new;
-        double cost_new = cost;
-        while (actual <= 0 && res.nfev < max_nfev) {
-            Vec<N> p_h, p, step, step_h;
-            solve_lsq_trust_region<N>(m, uf, sv, Vm, Delta, alpha, p_h);
-#pragma unroll
-            for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
-            double predicted;
-            TRF_T(3);
-            if (!select_step<N>(x, T, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h, predicted)) {
-                res.status = TRF_FAIL_GEOMETRY;
-                return res;
-            }
-#pragma unroll
-            for (int i = 0; i < N; ++i) x_new[i] = x[i] + step[i];
-            make_strictly_feasible(x_new, lb, ub, 0.0);
-            TRF_T(4);
-            double c2;
-            bool f_ok;
-            residual(x_new, S.rn, c2, f_ok);
-            res.nfev += 1;
-            TRF_T(5);
-            const double step_h_norm = vnorm(step_h);
-            if (!f_ok) { Delta = 0.25 * step_h_norm; continue; }
-            cost_new = 0.5 * c2;
-            actual = cost - cost_new;
-            // update_tr_radius (common.py:222-248)
-            double ratio;
-            if (predicted > 0) ratio = actual / predicted;
-            else if (predicted == 0 && actual == 0) ratio = 1;
-            else ratio = 0;
-            double Delta_new = Delta;
-            if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
-            else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
-            // check_termination (common.py:705-717)
-            const double step_norm = vnorm(step), x_norm = vnorm(x);
-            const bool ftol_ok = (actual < ftol * cost) && (ratio > 0.25);
-            const bool xtol_ok = step_norm < xtol * (xtol + x_norm);
-            if (ftol_ok && xtol_ok) status = 4;
-            else if (ftol_ok) status = 2;
-            else if (xtol_ok) status = 3;
-            if (status != -99) break;
-            alpha *= Delta / Delta_new;
-            Delta = Delta_new;
-        }
-        if (actual > 0) {
-            x = x_new;
-            W::sync();
-            for (int i = lane; i < m; i += W::LANES) S.r[i] = S.rn[i];
-            cost = cost_new;
-            W::sync();
-            // scipy recomputes J here even when terminating; curve_fit then takes an SVD of it
-            // (check_finite) -> a non-finite final Jacobian is a failure too.
-            TRF_T(6);
-            jacobian(x, g, fin);
-            TRF_T(7);
-            if (!fin) { res.status = TRF_FAIL_NONFINITE; return res; }
-        }
-    }
-    res.status = (status == -99) ? TRF_FAIL_MAXFEV : status;
-    return res;
+    x = Z.x;
+    return Z.res;
 }
 
 }  // namespace lcfe
