@@ -327,10 +327,16 @@ __global__ __launch_bounds__(64, 2) void bazin_partition_kernel(BatchView B, Bin
 #pragma unroll
             for (int b = 0; b < 6; ++b) { const int m = L.boff[b + 1] - L.boff[b]; mb = (m > mb) ? m : mb; }
             if (mb > kFitCaps[kFitTiers - 1]) {
-                // a band beyond the largest fit tier: the whole object goes to the object-level kernel
-                if (threadIdx.x == 0) {
-                    const int slot = atomicAdd(&bins.counts[kBazinFallbackList], 1);
-                    bins.lists[(int64_t)kBazinFallbackList * bins.stride + slot] = (int)i;
+                // a band beyond the largest fit tier: the whole object goes to the object-level kernel, which takes
+                // light curves of up to 1024 rows; beyond that the fit is not available (NaN, status -100)
+                if (n <= 1024) {
+                    if (threadIdx.x == 0) {
+                        const int slot = atomicAdd(&bins.counts[kBazinFallbackList], 1);
+                        bins.lists[(int64_t)kBazinFallbackList * bins.stride + slot] = (int)i;
+                    }
+                } else {
+                    fill_row_nan<W>(out + i * (int64_t)ld + col0, BAZIN_NCOL);
+                    if (status && threadIdx.x < 12) status[i * (int64_t)st_ld + st0 + threadIdx.x] = -100;
                 }
             } else if (threadIdx.x < 6) {
                 const int b = threadIdx.x;
@@ -569,6 +575,7 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
     __shared__ unsigned short rows[ROWCAP], rows2[ROWCAP];
     __shared__ double orow[GP1D_NCOL + 3];
     __shared__ int boff[5], nvalid[4];
+    __shared__ int wcnt[T / 64][4];
     __shared__ long long next_ticket;
     const int count = bins.counts[kNumBins + bin];
     const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
@@ -601,14 +608,31 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
             for (int j = 0; j < 4; ++j) { boff[j + 1] = boff[j] + cnt[j]; nvalid[j] = nv[j]; }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += T) {
-            const int band = bb[k];
-            if (band < 1 || band > 4) continue;
-            int p = 0;
-            for (int q = 0; q < k; ++q) p += (bb[q] == band) ? 1 : 0;
-            rows[boff[band - 1] + p] = (unsigned short)k;
+        // stable partition by band: ballot ranks inside a wavefront, wave totals through LDS, running totals per chunk
+        // (one pass over the band bytes instead of one scan of all earlier rows per row)
+        {
+            int run[4] = {0, 0, 0, 0};
+            for (int base = 0; base < n; base += T) {
+                const int k = base + (int)threadIdx.x;
+                const int band = (k < n) ? (int)bb[k] : 0;
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long mk = __ballot(band == j + 1);
+                    if (band == j + 1) rank = WaveDev::prefix(mk);
+                    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6][j] = popcll(mk);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int before = 0, total = 0;
+                    for (int wv = 0; wv < T / 64; ++wv) { const int c = wcnt[wv][j]; total += c; before += (wv < (int)(threadIdx.x >> 6)) ? c : 0; }
+                    if (band == j + 1) rows[boff[j] + run[j] + before + rank] = (unsigned short)k;
+                    run[j] += total;
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
         bool ordered = true;
         for (int k = threadIdx.x; k + 1 < n; k += T) ordered = ordered && (t[k] <= t[k + 1]);
         if (!W::all(ordered)) {
@@ -826,7 +850,7 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
     F.fits = (int*)p;
     F.fit_stride = 6 * (int64_t)no;
     int last = 0;
-    while (last < 3 && kTiers[last] < max_len) ++last;
+    while (last < 4 && kTiers[last] < max_len) ++last;
     unsigned long long* tk = tickets + SET_BAZIN * 8;
     for (int ti = 0; ti <= last; ++ti) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
@@ -836,6 +860,7 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
             case 1: rc = launch_bazin_partition<256>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
             case 2: rc = launch_bazin_partition<512>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
             case 3: rc = launch_bazin_partition<1024>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 4: rc = launch_bazin_partition<2048>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
         }
         if (rc) return rc;
         ++*n_launch;

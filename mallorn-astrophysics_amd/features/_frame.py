@@ -8,7 +8,7 @@ from ..packing import pack_lightcurves
 
 # longest light curve (rows) a feature set's largest kernel tier takes; longer objects (bands, for the per-band GP)
 # come back as NaN with status -100 where the reference would compute values (INTEGRATION.md "Limits")
-SET_LIMITS = {"bazin": 1024, "powerlaw": 1024, "gp2d": 767, "gp1d": 767}
+SET_LIMITS = {"bazin": 2048, "powerlaw": 1024, "gp2d": 767, "gp1d": 767, "research": 1024}
 
 
 def _extract_and_warn(set_name, csr, z, kept):

@@ -418,7 +418,7 @@ def test_over_long_objects_are_reported_not_silent():
     from mallorn_astrophysics_amd.features.bazin_fitting import extract_bazin_features
     rng = np.random.default_rng(12)
     objs = []
-    for n in (60, 1100):
+    for n in (60, 2100):                     # Bazin takes light curves of up to 2048 rows
         t = np.sort(59000 + rng.uniform(0, 400, n))
         objs.append((t, rng.normal(10, 3, n), np.full(n, 1.0), rng.choice(6, n)))
     lc = synth.from_objects(objs)
@@ -426,3 +426,26 @@ def test_over_long_objects_are_reported_not_silent():
     with pytest.warns(RuntimeWarning, match="long"):
         out = extract_bazin_features(df, ["short", "long"])
     assert np.isnan(out[COLUMNS["bazin"]].to_numpy(float)[1]).all()
+
+
+def test_bazin_long_light_curves_vs_oracle():
+    """Light curves of 1025..2048 rows used to come back as NaN (the object-level kernel keeps a whole light curve in
+    LDS); the fit-by-fit path only needs one BAND (up to 256 rows) in LDS, so they are fitted like the reference does
+    (bazin_fitting.py:76-93 has no cap)."""
+    rng = np.random.default_rng(31)
+    objs = []
+    for n in (1100, 1530, 2046):             # <= 184, <= 256 and 341 rows per band: the last one exceeds the 256-row tier
+        t = np.sort(59000 + rng.uniform(0, 600, n))
+        b = rng.permutation(np.repeat(np.arange(6), n // 6 + 1)[:n])
+        f = 40 * np.exp(-(t - 59200) / 60) / (1 + np.exp(-(t - 59200) / 8)) * (1 + 0.1 * b) + 3 + rng.normal(0, 1.5, n)
+        objs.append((t, f, np.full(n, 1.5), b))
+    lc = synth.from_objects(objs)
+    got, st = extract_csr("bazin", lc, return_status=True)
+    assert np.isnan(got[2]).all() and (st[2] == -100).all()
+    keep = synth.from_objects(objs[:2])
+    ref = oracle.extract("bazin", keep)
+    assert np.array_equal(np.isnan(got[:2]), np.isnan(ref))
+    both = ~np.isnan(ref)
+    rel = np.abs(got[:2] - ref)[both] / np.maximum(np.abs(ref[both]), 1e-9)
+    assert (rel <= 1e-4).mean() >= 0.9, (rel <= 1e-4).mean()
+    assert (st[:2, 0::2] > 0).all()
