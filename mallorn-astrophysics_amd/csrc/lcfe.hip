@@ -899,22 +899,42 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
 // Statistics: lean kernels for the tiers up to 512 rows, the general kernel for the longer tiers,
 // for the lean kernels' fallback list and for the NaN rows of over-long objects.
 int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0,
-                hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
+                hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, hipStream_t s1, hipStream_t s2) {
     int last = 0;
     while (last < 4 && kTiers[last] < max_len) ++last;
     unsigned long long* tk = tickets + SET_STAT * 8;
+    // the tier kernels are independent (disjoint objects): with side streams they are enqueued side by side, so the
+    // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch
+    const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
+    hipEvent_t ev_fork = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
+    struct Cleanup { hipEvent_t* e[3]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_j1, &ev_j2}};
+    if (fork) {
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(s1, ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
+    }
     for (int ti = 0; ti <= last; ++ti) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        hipStream_t q = !fork ? stream : ((ti % 3 == 0) ? stream : ((ti % 3 == 1) ? s1 : s2));
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
-            case 1: rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
-            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, stream, dev, tk + ti); break;
-            case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + ti); break;
-            case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + ti); break;
+            case 0: rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 1: rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
+            case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
         }
         if (rc) return rc;
         ++*n_launch;
+    }
+    if (fork) {
+        HIP_TRY(hipEventCreateWithFlags(&ev_j1, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_j2, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_j1, s1));
+        HIP_TRY(hipEventRecord(ev_j2, s2));
+        HIP_TRY(hipStreamWaitEvent(stream, ev_j1, 0));
+        HIP_TRY(hipStreamWaitEvent(stream, ev_j2, 0));
     }
     // fallback list of the lean tiers (+ the NaN rows when no general tier ran): normally empty or a
     // handful of objects, so a quarter-chip grid keeps the launch short
@@ -1147,7 +1167,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if (prof && ne != 0) HIP_TRY(hipEventRecord(ev0[s], q));
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets); break;
+            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets, fork ? side[0] : q, fork ? side[1] : q); break;
             case SET_BAZIN: rc = launch_bazin(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, bazin_ws, bazin_bytes, n_points); break;
             case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
