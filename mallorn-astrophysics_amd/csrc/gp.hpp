@@ -364,7 +364,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                         }
                         const gp_v4f64 w1 = w_alayout(dA1, S.V, i);
                         const double n1[4] = {-w1[0], -w1[1], -w1[2], -w1[3]};
-                        constexpr int UNR = 2;
+                        constexpr int UNR = 2;      // tiles in flight (four were measured slower, also at 256 registers per lane)
                         for (int j0 = 0; j0 <= i; j0 += UNR) {
                             gp_v4f64 c[UNR];
                             double b1[UNR][4], b2[UNR][4];

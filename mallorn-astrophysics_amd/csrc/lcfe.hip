@@ -446,14 +446,14 @@ constexpr size_t kGpSmallBytes = (size_t)kGpSmallGrid * gp_store_doubles(kGpSmal
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
 
-template <int NP> struct gp_threads { static constexpr int T = (NP >= 480) ? 1024 : ((NP >= 160) ? 512 : 256); };
+template <int NP> struct gp_threads { static constexpr int T = (NP >= 768) ? 1024 : ((NP >= 160) ? 512 : 256); };
 // the two global-scratch tiers whose second pivot panel fits LDS sweep two pivot tiles per pass over the matrix
 template <int NP, bool GLOBAL_K> struct gp_fuse { static constexpr bool F = GLOBAL_K && NP <= 480; };
 template <int NP> struct gp_grid_cap { static constexpr int G = (NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid; };
 
 // waves per SIMD to leave room for: the 64- and 112-row tiers fit two or more workgroups per CU in LDS,
 // so their register budget is halved (the L-BFGS-B driver spills a little, the sweep does not)
-template <int NP> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : ((NP <= 160) ? 2 : 4); };
+template <int NP> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : ((NP <= 160 || NP == 480) ? 2 : 4); };
 
 template <int NP, bool GLOBAL_K>
 __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
