@@ -238,13 +238,20 @@ LCFE_FN TrfView<N> powerlaw_view(PowerlawLds<CAP>& S, int off) {
     return v;
 }
 
-// one bounded fit of `model` to the k post-peak rows (tp, fp) -> R^2   (train_v55_powerlaw.py:170-192)
-template <class W, class M>
-LCFE_FN TrfResult decline_fit(const M& model, const double* tp, const double* fp, int k, double peak_flux,
-                              double ss_tot, int kind, TrfView<M::NP>& T, double* out) {
-    constexpr int N = M::NP;
-    const int lane = W::lane();
-    Vec<N> x, lb, ub;
+// exponential and linear decline models behind one type (the three-parameter fit kernel runs both side by side)
+struct Decline3Model {
+    static constexpr int NP = 3;
+    int kind;                  // 7: exponential, 8: linear
+    LCFE_FN double operator()(double t, const Vec<3>& x) const {
+        if (kind == 7) return x[0] * exp(-fmax(t - x[2], 0.0) / x[1]);
+        return x[0] - x[1] * fmax(t - x[2], 0.0);
+    }
+};
+
+// start point and bounds of a decline fit (train_v55_powerlaw.py:172-184); kind 0..6 power laws, 7 exponential, 8 linear
+template <int N>
+LCFE_FN void decline_setup(int kind, double peak_flux, TrfState<N>& Z) {
+    Vec<N>& x = Z.x; Vec<N>& lb = Z.lb; Vec<N>& ub = Z.ub;
     if (N == 2) {                                                 // :172-175
         x[0] = peak_flux; x[1] = 0;
         lb[0] = 0; lb[1] = -10; ub[0] = 1e6; ub[1] = 10;
@@ -255,18 +262,72 @@ LCFE_FN TrfResult decline_fit(const M& model, const double* tp, const double* fp
         x[0] = peak_flux; x[1] = 1; x[N - 1] = 0;
         lb[0] = 0; lb[1] = 0; lb[N - 1] = -10; ub[0] = 1e6; ub[1] = 100; ub[N - 1] = 10;
     }
-    for (int i = lane; i < k; i += W::LANES) T.w[i] = 1.0;        // unweighted: r = model - y
-    W::sync();
-    TrfResult res = trf_fit<W, M, TrfView<N>>(model, tp, fp, k, x, lb, ub, 1000, T);
-    if (res.status <= 0) {                                        // :191-192
+    Z.max_nfev = 1000;                                            // maxfev=1000
+}
+
+// R^2 of a finished decline fit (:186-192) -> *out
+template <class W, class M>
+LCFE_FN void decline_finish(const M& model, const double* tp, const double* fp, int k, double ss_tot,
+                            const TrfState<M::NP>& Z, double* out) {
+    const int lane = W::lane();
+    if (Z.res.status <= 0) {                                      // :191-192
         if (lane == 0) *out = qnan();
-        return res;
+        return;
     }
     double ss = 0;
-    for (int i = lane; i < k; i += W::LANES) { const double r = fp[i] - model(tp[i], x); ss += r * r; }   // :186-187
+    for (int i = lane; i < k; i += W::LANES) { const double r = fp[i] - model(tp[i], Z.x); ss += r * r; }   // :186-187
     ss = W::sum(ss);
     if (lane == 0) *out = (ss_tot > 0) ? 1.0 - ss / ss_tot : 0.0;       // :189
-    return res;
+}
+
+// one bounded fit of `model` to the k post-peak rows (tp, fp) -> R^2   (train_v55_powerlaw.py:170-192)
+template <class W, class M>
+LCFE_FN TrfResult decline_fit(const M& model, const double* tp, const double* fp, int k, double peak_flux,
+                              double ss_tot, int kind, TrfView<M::NP>& T, double* out) {
+    constexpr int N = M::NP;
+    const int lane = W::lane();
+    TrfState<N> Z;
+    decline_setup<N>(kind, peak_flux, Z);
+    for (int i = lane; i < k; i += W::LANES) T.w[i] = 1.0;        // unweighted: r = model - y
+    W::sync();
+    trf_begin<W, M, TrfView<N>>(model, tp, fp, k, Z, T);
+    while (Z.phase != TRF_PH_DONE) {
+        if (Z.phase == TRF_PH_OUTER) trf_outer<W, M, TrfView<N>>(k, Z, T);
+        else trf_inner<W, M, TrfView<N>>(model, tp, fp, k, Z, T);
+    }
+    decline_finish<W, M>(model, tp, fp, k, ss_tot, Z, out);
+    return Z.res;
+}
+
+// train_v55_powerlaw.py:147-166 for one band's time-sorted rows: peak, post-peak rows (times relative to the peak and
+// fluxes -> tp, fp), their total sum of squares.  k = -1: no fits for this band.
+template <class W>
+LCFE_FN void powerlaw_band_prepare(const double* t, const double* f, int m, double* tp, double* fp, int& k, int& first,
+                                   double& peak_flux, double& ss_tot) {
+    k = -1; first = 0; peak_flux = 0; ss_tot = 0;
+    if (m >= 5) {                                             // :150-151
+        const int pk = wave_argmax_first<W>(f, m);            // :157
+        const double peak_time = t[pk];
+        peak_flux = f[pk];
+        first = m;
+        for (int i = W::lane(); i < m; i += W::LANES) if (t[i] > peak_time) first = (i < first) ? i : first;   // :161
+        first = W::min(first);
+        k = m - first;
+        if (k < 3) k = -1;                                    // :162-163
+        else {
+            double sum = 0;
+            for (int i = W::lane(); i < k; i += W::LANES) {
+                tp[i] = t[first + i] - peak_time;             // :165
+                fp[i] = f[first + i];
+                sum += f[first + i];
+            }
+            const double mean_post = W::sum(sum) / k;
+            W::sync();
+            double q = 0;
+            for (int i = W::lane(); i < k; i += W::LANES) { const double d = fp[i] - mean_post; q += d * d; }   // :188
+            ss_tot = W::sum(q);
+        }
+    }
 }
 
 // W: policy of ONE FIT (an 8-lane group on the device: up to six fits side by side -- three bands x
@@ -280,31 +341,9 @@ LCFE_FN void powerlaw_object(const ObjLds<CAP>& L, PowerlawLds<CAP>& S, int32_t*
         const int s = L.boff[kb], m = L.boff[kb + 1] - s;
         const double* t = L.bt + s;
         const double* f = L.bf + s;
-        int k = -1, first = 0;
-        double peak_flux = 0, ss_tot = 0;
-        if (m >= 5) {                                             // :150-151
-            const int pk = wave_argmax_first<W>(f, m);            // :157
-            const double peak_time = t[pk];
-            peak_flux = f[pk];
-            first = m;
-            for (int i = W::lane(); i < m; i += W::LANES) if (t[i] > peak_time) first = (i < first) ? i : first;   // :161
-            first = W::min(first);
-            k = m - first;
-            if (k < 3) k = -1;                                    // :162-163
-            else {
-                double sum = 0;
-                for (int i = W::lane(); i < k; i += W::LANES) {
-                    S.tp[s + i] = t[first + i] - peak_time;       // :165
-                    S.fp[s + i] = f[first + i];
-                    sum += f[first + i];
-                }
-                const double mean_post = W::sum(sum) / k;
-                W::sync();
-                double q = 0;
-                for (int i = W::lane(); i < k; i += W::LANES) { const double d = S.fp[s + i] - mean_post; q += d * d; }   // :188
-                ss_tot = W::sum(q);
-            }
-        }
+        int k, first;
+        double peak_flux, ss_tot;
+        powerlaw_band_prepare<W>(t, f, m, S.tp + s, S.fp + s, k, first, peak_flux, ss_tot);
         if (W::lane() == 0) { S.k[j] = k; S.first[j] = first; S.peak[j] = peak_flux; S.sstot[j] = ss_tot; }
         W::sync();
     }

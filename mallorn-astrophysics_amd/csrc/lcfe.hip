@@ -70,9 +70,10 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 2;
+constexpr int kNumLists = 2 * kNumBins + 3;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
+constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -432,6 +433,166 @@ __global__ __launch_bounds__(256) void bazin_cross_kernel(BatchView B, double* o
     for (int k = 0; k < 48; ++k) o[k] = row[k];
     bazin_cross_band(o);
     for (int k = 48; k < 52; ++k) row[k] = o[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Decline-model fits (v55 power-law set), fit by fit: same scheme as the Bazin fits above.  A partition pass writes,
+// per object and band g/r/i, the post-peak rows (times relative to the peak, fluxes) and their peak flux and total
+// sum of squares, and queues the band's nine fits: the seven power laws (two parameters, the exponent is data) in
+// list A, the exponential and the linear model (three parameters) in list B, per tier of the post-peak row count.
+constexpr int kPlCountA = 40, kPlCountB = 44;               // counts[40 + t], counts[44 + t]
+constexpr int kPlTicketA = 104, kPlTicketB = 108;           // tickets[...]
+struct PlWs {
+    double* tp;            // post-peak times of band j of object i at offsets[i] + boff[j + 1] ..., indexed like the CSR arrays
+    double* fp;
+    double* peak;          // [n_obj][3]
+    double* sstot;         // [n_obj][3]
+    int* pboff;            // [n_obj][8]
+    int* kk;               // [n_obj][3] post-peak rows (-1: no fits)
+    int* fitsA;            // [kFitTiers][21 n_obj]   ids: object * 32 + band * 9 + model
+    int* fitsB;            // [kFitTiers][6 n_obj]
+    int64_t strideA, strideB;
+};
+
+template <int N, int BCAP>
+struct PlRegion {
+    double t[BCAP], f[BCAP];
+    double r[BCAP], rn[BCAP], w[BCAP];
+    double A[N + 1][BCAP + N];
+};
+
+template <int CAP>
+__global__ __launch_bounds__(64, 2) void powerlaw_partition_kernel(BatchView B, Bins bins, int bin, int nan_from, PlWs F, double* out, int ld,
+                                                                   int col0, int32_t* status, int st_ld, int st0,
+                                                                   unsigned long long* ticket, int chunk) {
+    __shared__ ObjLds<CAP> L;
+    __shared__ long long next_ticket;
+    using W = WaveDev;
+    const int count = bins.counts[bin];
+    const int* list = bins.lists + (int64_t)bin * bins.stride;
+    const int per_wave = count / (4 * (int)gridDim.x);
+    chunk = (per_wave < 1) ? 1 : ((per_wave < chunk) ? per_wave : chunk);
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t base = next_ticket * chunk;
+        __syncthreads();
+        if (base >= count) break;
+        const int nk = (count - base < chunk) ? (int)(count - base) : chunk;
+        for (int q = 0; q < nk; ++q) {
+            const int64_t i = list[base + q];
+            const int64_t s = B.offsets[i];
+            const int n = (int)(B.offsets[i + 1] - s);
+            ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, n, qnan()};
+            stage_object<W, CAP>(in, L);
+            if (threadIdx.x < 8) F.pboff[i * 8 + threadIdx.x] = L.boff[threadIdx.x];
+            int kb[3];
+            for (int j = 0; j < 3; ++j) {
+                const int b0 = L.boff[j + 1], m = L.boff[j + 2] - b0;
+                int k, first;
+                double peak_flux, ss_tot;
+                powerlaw_band_prepare<W>(L.bt + b0, L.bf + b0, m, F.tp + s + b0, F.fp + s + b0, k, first, peak_flux, ss_tot);
+                kb[j] = k;
+                if (threadIdx.x == 0) { F.kk[i * 3 + j] = k; F.peak[i * 3 + j] = peak_flux; F.sstot[i * 3 + j] = ss_tot; }
+            }
+            const int kmax = (kb[0] > kb[1]) ? ((kb[0] > kb[2]) ? kb[0] : kb[2]) : ((kb[1] > kb[2]) ? kb[1] : kb[2]);
+            if (kmax > kFitCaps[kFitTiers - 1]) {
+                // more post-peak rows than the largest fit tier: object-level kernel (up to 1024 rows), else not available
+                if (n <= 1024) {
+                    if (threadIdx.x == 0) {
+                        const int slot = atomicAdd(&bins.counts[kPowerlawFallbackList], 1);
+                        bins.lists[(int64_t)kPowerlawFallbackList * bins.stride + slot] = (int)i;
+                    }
+                } else {
+                    fill_row_nan<W>(out + i * (int64_t)ld + col0, POWERLAW_NCOL);
+                    if (status && threadIdx.x < 54) status[i * (int64_t)st_ld + st0 + threadIdx.x] = -100;
+                }
+            } else if (threadIdx.x < 3) {
+                const int j = threadIdx.x;
+                const int k = kb[j];
+                if (k < 0) {                                                    // train_v55_powerlaw.py:150-151,162-163
+                    double* o9 = out + i * (int64_t)ld + col0 + 9 * j;
+                    for (int id = 0; id < 9; ++id) {
+                        o9[id] = qnan();
+                        if (status) { status[i * (int64_t)st_ld + st0 + 18 * j + 2 * id] = TRF_FAIL_TOO_FEW; status[i * (int64_t)st_ld + st0 + 18 * j + 2 * id + 1] = 0; }
+                    }
+                } else {
+                    const int tier = (k <= kFitCaps[0]) ? 0 : ((k <= kFitCaps[1]) ? 1 : ((k <= kFitCaps[2]) ? 2 : 3));
+                    const int a0 = atomicAdd(&bins.counts[kPlCountA + tier], 7);
+                    for (int id = 0; id < 7; ++id) F.fitsA[tier * F.strideA + a0 + id] = (int)i * 32 + j * 9 + id;
+                    const int b0 = atomicAdd(&bins.counts[kPlCountB + tier], 2);
+                    F.fitsB[tier * F.strideB + b0] = (int)i * 32 + j * 9 + 7;
+                    F.fitsB[tier * F.strideB + b0 + 1] = (int)i * 32 + j * 9 + 8;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    nan_fill_bins<W>(bins, 0, nan_from, out, ld, col0, POWERLAW_NCOL, status, st_ld, st0, 54);
+}
+
+// N = 2: the seven power laws (PowerModel, exponent from the fit id); N = 3: exponential and linear (Decline3Model)
+template <int N> struct pl_model;
+template <> struct pl_model<2> { using type = PowerModel; static __device__ __forceinline__ PowerModel make(int id) { return PowerModel{decline_exponent(id)}; } };
+template <> struct pl_model<3> { using type = Decline3Model; static __device__ __forceinline__ Decline3Model make(int id) { return Decline3Model{id}; } };
+
+template <int N, int BCAP>
+__global__ __launch_bounds__(64, (BCAP <= 64 ? 2 : 1)) void powerlaw_fit_kernel(BatchView B, Bins bins, PlWs F, int tier, double* out, int ld,
+                                                                                  int col0, int32_t* status, int st_ld, int st0,
+                                                                                  unsigned long long* ticket) {
+    using G = GroupDev<8>;
+    using M = typename pl_model<N>::type;
+    constexpr int NG = fit_groups<BCAP>::N;
+    __shared__ PlRegion<N, BCAP> R[NG];
+    PlRegion<N, BCAP>& Rg = R[(G::group_id() < NG) ? G::group_id() : 0];
+    TrfView<N> V;
+#pragma unroll
+    for (int k = 0; k <= N; ++k) V.A[k] = Rg.A[k];
+    V.r = Rg.r; V.rn = Rg.rn; V.w = Rg.w;
+    const int count = bins.counts[((N == 2) ? kPlCountA : kPlCountB) + tier];
+    const int* list = (N == 2) ? F.fitsA + (int64_t)tier * F.strideA : F.fitsB + (int64_t)tier * F.strideB;
+    const int gl = G::lane();
+    const int leader = (int)(threadIdx.x & 63) & ~7;
+    TrfState<N> Z;
+    Z.phase = (G::group_id() < NG) ? FIT_IDLE : FIT_EXIT;
+    M model = pl_model<N>::make(N == 2 ? 0 : 7);
+    int k = 0, id = 0, j = 0;
+    int64_t obj = 0;
+    double ss_tot = 0;
+    for (;;) {
+        if (Z.phase == FIT_IDLE) {
+            int tk = 0;
+            if (gl == 0) tk = (int)atomicAdd(ticket, 1ull);
+            tk = __shfl(tk, leader, 64);
+            if (tk >= count) Z.phase = FIT_EXIT;
+            else {
+                const int fid = list[tk];
+                obj = fid >> 5;
+                j = (fid & 31) / 9;
+                id = (fid & 31) - 9 * j;
+                k = F.kk[obj * 3 + j];
+                ss_tot = F.sstot[obj * 3 + j];
+                const int64_t src = B.offsets[obj] + F.pboff[obj * 8 + j + 1];
+                for (int i = gl; i < k; i += 8) { Rg.t[i] = F.tp[src + i]; Rg.f[i] = F.fp[src + i]; Rg.w[i] = 1.0; }
+                model = pl_model<N>::make(id);
+                decline_setup<N>(id, F.peak[obj * 3 + j], Z);
+                G::sync();
+                trf_begin<G, M, TrfView<N>>(model, Rg.t, Rg.f, k, Z, V);
+            }
+        }
+        if (__ballot(Z.phase != FIT_EXIT) == 0ull) break;
+        if (Z.phase == TRF_PH_OUTER) trf_outer<G, M, TrfView<N>>(k, Z, V);
+        if (Z.phase == TRF_PH_INNER) trf_inner<G, M, TrfView<N>>(model, Rg.t, Rg.f, k, Z, V);
+        if (Z.phase == TRF_PH_DONE) {
+            decline_finish<G, M>(model, Rg.t, Rg.f, k, ss_tot, Z, out + obj * (int64_t)ld + col0 + 9 * j + id);
+            if (status && gl == 0) {
+                status[obj * (int64_t)st_ld + st0 + 18 * j + 2 * id] = Z.res.status;
+                status[obj * (int64_t)st_ld + st0 + 18 * j + 2 * id + 1] = Z.res.nfev;
+            }
+            G::sync();
+            Z.phase = FIT_IDLE;
+        }
+    }
 }
 
 int num_cus(int dev);
@@ -881,6 +1042,90 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
     return 0;
 }
 
+size_t powerlaw_ws_bytes(int64_t n_obj, int64_t n_points) {
+    const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)(n_obj > 0 ? n_obj : 1);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(2 * 8 * np) + al(2 * 3 * 8 * no) + al(32 * no) + al(12 * no) + al(4 * (size_t)kFitTiers * 21 * no) + al(4 * (size_t)kFitTiers * 6 * no);
+}
+
+template <int CAP>
+int launch_powerlaw_partition(const BatchView& B, const Bins& bins, int bin, int nan_from, const PlWs& F, double* out, int ld, int col0,
+                              int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, powerlaw_partition_kernel<CAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((powerlaw_partition_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, nan_from, F, out, ld,
+                       col0, status, st_ld, st0, ticket, 8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int N, int BCAP>
+int launch_powerlaw_fits(const BatchView& B, const Bins& bins, const PlWs& F, int tier, double* out, int ld, int col0, int32_t* status,
+                         int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (powerlaw_fit_kernel<N, BCAP>), 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    const int64_t nfit = ((N == 2) ? 21 : 6) * B.n_obj;
+    if (grid * 8 > nfit) grid = (nfit + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((powerlaw_fit_kernel<N, BCAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, F, tier, out, ld, col0, status,
+                       st_ld, st0, ticket);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
+                    int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, void* ws, size_t ws_bytes,
+                    int64_t n_points) {
+    if (!ws || ws_bytes < powerlaw_ws_bytes(B.n_obj, n_points))
+        return fail_msg("lcfe_extract_device: workspace too small for the decline-fit lists");
+    const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)B.n_obj;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    PlWs F;
+    char* p = (char*)ws;
+    F.tp = (double*)p; F.fp = F.tp + np; p += al(2 * 8 * np);
+    F.peak = (double*)p; F.sstot = F.peak + 3 * no; p += al(2 * 3 * 8 * no);
+    F.pboff = (int*)p; p += al(32 * no);
+    F.kk = (int*)p; p += al(12 * no);
+    F.fitsA = (int*)p; p += al(4 * (size_t)kFitTiers * 21 * no);
+    F.fitsB = (int*)p;
+    F.strideA = 21 * (int64_t)no;
+    F.strideB = 6 * (int64_t)no;
+    int last = 0;
+    while (last < 4 && kTiers[last] < max_len) ++last;
+    unsigned long long* tk = tickets + SET_POWERLAW * 8;
+    for (int ti = 0; ti <= last; ++ti) {
+        const int nan_from = (ti == last) ? ti + 1 : kNumBins;
+        int rc = 0;
+        switch (ti) {
+            case 0: rc = launch_powerlaw_partition<128>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 1: rc = launch_powerlaw_partition<256>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 2: rc = launch_powerlaw_partition<512>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 3: rc = launch_powerlaw_partition<1024>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+            case 4: rc = launch_powerlaw_partition<2048>(B, bins, ti, nan_from, F, out, ld, col0, status, st_ld, st0, stream, dev, tk + ti); break;
+        }
+        if (rc) return rc;
+        ++*n_launch;
+    }
+    int rc = 0;
+#define PL_TIER(BC, T)                                                                                                        \
+    if (!rc) rc = launch_powerlaw_fits<2, BC>(B, bins, F, T, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kPlTicketA + T); \
+    if (!rc) rc = launch_powerlaw_fits<3, BC>(B, bins, F, T, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kPlTicketB + T);
+    PL_TIER(256, 3) PL_TIER(128, 2) PL_TIER(64, 1) PL_TIER(32, 0)
+#undef PL_TIER
+    if (rc) return rc;
+    *n_launch += 8;
+    rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5);
+    if (rc) return rc;
+    ++*n_launch;
+    return 0;
+}
+
 template <int CAP>
 int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
                      int dev, unsigned long long* ticket) {
@@ -1057,6 +1302,7 @@ size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points) {
     size_t b = kWsHeader + list_bytes(n_obj);
     if (mask & (1 << SET_GP2D)) b += kGpSmallBytes + kGpMidBytes + kGpGlobalBytes;
     if (mask & (1 << SET_BAZIN)) b += bazin_ws_bytes(n_obj, n_points);
+    if (mask & (1 << SET_POWERLAW)) b += powerlaw_ws_bytes(n_obj, n_points);
     return b;
 }
 
@@ -1102,6 +1348,9 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     region += gp_scratch_bytes;
     void* bazin_ws = (mask & (1 << SET_BAZIN)) ? (void*)region : nullptr;
     const size_t bazin_bytes = bazin_ws ? bazin_ws_bytes(n_obj, n_points) : 0;
+    region += bazin_bytes;
+    void* pl_ws = (mask & (1 << SET_POWERLAW)) ? (void*)region : nullptr;
+    const size_t pl_bytes = pl_ws ? powerlaw_ws_bytes(n_obj, n_points) : 0;
     const Bins bins{lists, counts, n_obj};
     // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
     // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
@@ -1169,7 +1418,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         switch (s) {
             case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets, fork ? side[0] : q, fork ? side[1] : q); break;
             case SET_BAZIN: rc = launch_bazin(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, bazin_ws, bazin_bytes, n_points); break;
-            case SET_POWERLAW: rc = launch_set<SET_POWERLAW>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_POWERLAW: rc = launch_powerlaw(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, pl_ws, pl_bytes, n_points); break;
             case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
