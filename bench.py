@@ -270,7 +270,7 @@ def main():
     # HBM traffic of the roofline kernel from PMC counters (collected offline in separate rocprofv3
     # --pmc passes on this exact workload; bench.py cannot run under the counters itself)
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01_stat_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r02_stat_traffic.json")
     if rk == "stat" and world == 1 and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
         traffic = json.load(open(tj)).get("hbm_bytes_per_pass")
     res = {

@@ -23,5 +23,6 @@ for k, nm in ((8, "median"), (9, "iqr"), (10, "mad")):
     names[24 + k] = "  band group 0: " + nm
 tot = sum(buf[k] for k in range(6))
 for k in sorted(names):
-    print(f"{names[k]:34s} {buf[k] / n:9.0f} cycles/object {100 * buf[k] / tot:5.1f}%")
+    if k < 32:
+        print(f"{names[k]:34s} {buf[k] / n:9.0f} cycles/object {100 * buf[k] / tot:5.1f}%")
 print("total cycles/object", tot / n)
