@@ -15,11 +15,11 @@ import numpy as np
 
 # Cost model of one object with N rows, in GPU-seconds of one MI355X (a N + b N^3 when the GP is on;
 # an N^2 term covers the latency-bound part of the small GP tiers).  Coefficients fitted to the per-tier kernel
-# times of profiles/r02_bench_serial_kernel_stats.csv (125,000 objects): streaming sets + bounded fits 1.14 s per
-# 16.95 M points; GP tiers 64/112/160/240/512 rows: 0.022/0.16/0.34/0.48/0.80 s for 13/42/34/25/10 k objects.
-COST_POINT = 6.7e-8
-COST_GP_N2 = 4.1e-10
-COST_GP_N3 = 1.15e-12
+# times of profiles/r02_bench_serial_kernel_stats.csv (125,000 objects): streaming sets + bounded fits 0.81 s per
+# 16.95 M points; GP tiers 64/112/160/240/480+768 rows: 0.021/0.148/0.315/0.391/0.636 s for 13/42/34/25/10 k objects.
+COST_POINT = 4.8e-8
+COST_GP_N2 = 4.6e-10
+COST_GP_N3 = 5.1e-13
 GP_SETS = ("gp2d", "gp1d")
 
 
