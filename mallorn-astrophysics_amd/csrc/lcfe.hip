@@ -606,18 +606,27 @@ constexpr int kGpSmallGrid = 512;
 constexpr size_t kGpSmallBytes = (size_t)kGpSmallGrid * gp_store_doubles(kGpSmallNP) * 8;
 constexpr size_t kGpMidBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpMidNP) * 8;
 constexpr size_t kGpGlobalBytes = (size_t)kGpGlobalGrid * gp_store_doubles(kGpGlobalNP) * 8;
+// the 112- and 160-row tiers can keep their matrix in global scratch as well (L2-resident slabs): the LDS then holds
+// only the two pivot panels, two to four workgroups share a CU and the sweep takes two pivot tiles per pass.  Measured
+// (125,000 objects): serialised, both tiers gain 8-9 %; with the fit kernels running beside the GP (the default
+// schedule) the 112-row tier in global scratch gains 1.5 % end to end and the 160-row tier LOSES 5 % -- so only the former.
+constexpr bool kGp112Global = true, kGp160Global = false;
+constexpr int kGp112Grid = 1024, kGp160Grid = 512;
+constexpr size_t kGp112Bytes = kGp112Global ? (size_t)kGp112Grid * gp_store_doubles(112) * 8 : 0;
+constexpr size_t kGp160Bytes = kGp160Global ? (size_t)kGp160Grid * gp_store_doubles(160) * 8 : 0;
+constexpr size_t kGpScratchBytes = kGpSmallBytes + kGpMidBytes + kGpGlobalBytes + kGp112Bytes + kGp160Bytes;
 
 template <int NP> struct gp_threads { static constexpr int T = (NP >= 768) ? 1024 : ((NP >= 160) ? 512 : 256); };
 // the two global-scratch tiers whose second pivot panel fits LDS sweep two pivot tiles per pass over the matrix
 template <int NP, bool GLOBAL_K> struct gp_fuse { static constexpr bool F = GLOBAL_K && NP <= 480; };
-template <int NP> struct gp_grid_cap { static constexpr int G = (NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid; };
+template <int NP> struct gp_grid_cap { static constexpr int G = (NP == 112) ? kGp112Grid : ((NP == 160) ? kGp160Grid : ((NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid)); };
 
 // waves per SIMD to leave room for: the 64- and 112-row tiers fit two or more workgroups per CU in LDS,
 // so their register budget is halved (the L-BFGS-B driver spills a little, the sweep does not)
-template <int NP> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : ((NP <= 160 || NP == 480) ? 2 : 4); };
+template <int NP, bool GLOBAL_K> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : (GLOBAL_K ? ((NP == 480) ? 2 : 4) : 2); };
 
 template <int NP, bool GLOBAL_K>
-__global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
+__global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch,
                                                  unsigned long long* ticket) {
     using W = BlockDev<gp_threads<NP>::T>;
@@ -679,11 +688,13 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     const int caps[6] = {63, 111, 159, kGpSmallNP - 1, kGpMidNP - 1, kGpGlobalNP - 1};
     int last = 0;
     while (last < 5 && caps[last] < max_len) ++last;
-    if (last >= 3 && kscratch_bytes < kGpSmallBytes + kGpMidBytes + kGpGlobalBytes)
+    if (kscratch_bytes < kGpScratchBytes)
         return fail_msg("lcfe_extract_device: workspace too small for the GP global tiers");
     double* k_small = kscratch;
     double* k_mid = kscratch + kGpSmallBytes / 8;
     double* k_glob = k_mid + kGpMidBytes / 8;
+    double* k_112 = k_glob + kGpGlobalBytes / 8;
+    double* k_160 = k_112 + kGp112Bytes / 8;
     // longest objects first, tiers alternating between two streams: the heavy-tailed end of one tier
     // (single objects of up to 50 ms) overlaps with the start of the next
     for (int ti = last, pos = 0; ti >= 0; --ti, ++pos) {
@@ -693,8 +704,8 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
         int rc = 0;
         switch (ti) {
             case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
-            case 1: rc = launch_gp_tier<112, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
-            case 2: rc = launch_gp_tier<160, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
+            case 1: rc = launch_gp_tier<112, kGp112Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_112, tk); break;
+            case 2: rc = launch_gp_tier<160, kGp160Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_160, tk); break;
             case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_small, tk); break;
             case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_mid, tk); break;
             case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_glob, tk); break;
@@ -1300,7 +1311,7 @@ static size_t list_bytes(int64_t n_obj) {
 }
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points) {
     size_t b = kWsHeader + list_bytes(n_obj);
-    if (mask & (1 << SET_GP2D)) b += kGpSmallBytes + kGpMidBytes + kGpGlobalBytes;
+    if (mask & (1 << SET_GP2D)) b += kGpScratchBytes;
     if (mask & (1 << SET_BAZIN)) b += bazin_ws_bytes(n_obj, n_points);
     if (mask & (1 << SET_POWERLAW)) b += powerlaw_ws_bytes(n_obj, n_points);
     return b;
@@ -1343,7 +1354,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         return fail_msg("lcfe_extract_device: workspace smaller than lcfe_workspace_bytes(mask, n_obj, n_points)");
     // after the lists: the GP scratch slabs (if the 2-D GP is in the mask), then the Bazin fit workspace
     char* region = (char*)d_workspace + kWsHeader + lists_b;
-    const size_t gp_scratch_bytes = (mask & (1 << SET_GP2D)) ? kGpSmallBytes + kGpMidBytes + kGpGlobalBytes : 0;
+    const size_t gp_scratch_bytes = (mask & (1 << SET_GP2D)) ? kGpScratchBytes : 0;
     double* gp_scratch = gp_scratch_bytes ? (double*)region : nullptr;
     region += gp_scratch_bytes;
     void* bazin_ws = (mask & (1 << SET_BAZIN)) ? (void*)region : nullptr;
