@@ -716,6 +716,9 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     return 0;
 }
 
+constexpr int kGp1dLongNP = 768;        // rows of the global-scratch matrix of a long band (160..767 valid points)
+constexpr int kGp1dLongGrid = 256;
+constexpr size_t kGp1dLongBytes = (size_t)kGp1dLongGrid * gp_store_doubles(kGp1dLongNP) * 8;
 constexpr int kGp1dThreads = 256;       // measured: 64 threads 10.1 s, 128: 7.2 s, 256: 6.8 s per 125 k objects
 // ---- per-band 1-D GP (gp1d.hpp): one light curve per workgroup of kGp1dThreads threads, its bands g, r, i, z one after
 // the other; the band's rows are an index list into the CSR slice (time order: file order when the rows
@@ -738,7 +741,7 @@ struct Gp1dBlockLds {
 template <int NP, int ROWCAP, int T, int WNP, int MW>
 __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                    int col0, int32_t* status, int st_ld, int st0,
-                                                   unsigned long long* ticket) {
+                                                   unsigned long long* ticket, double* kslab) {
     using W = BlockDev<T>;
     constexpr bool kWavePath = (T == 256);
     constexpr size_t kBlockBytes = sizeof(Gp1dBlockLds<NP, W::NWAVES>), kWaveBytes = kWavePath ? 4 * sizeof(Gp1dWaveLds<WNP>) : 0;
@@ -854,6 +857,24 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
                 __syncthreads();
             }
         }
+        // phase 3 (tier of 160..767 rows only): a band with more valid points than the LDS matrix takes has its Gram matrix
+        // in this workgroup's slab of global scratch; the working set of a kGp1dLongNP-row fit aliases the LDS buffer
+        if constexpr (ROWCAP > NP) {
+            if (kslab != nullptr && most + 1 > NP) {
+                static_assert(sizeof(GpLds<kGp1dLongNP, W::NWAVES>) <= sizeof(raw), "long-band working set must fit the LDS buffer");
+                auto& LG = *reinterpret_cast<GpLds<kGp1dLongNP, W::NWAVES>*>(raw);
+                double* Kg = kslab + (size_t)blockIdx.x * (size_t)gp_store_doubles(kGp1dLongNP);
+                for (int j = 0; j < 4; ++j) {
+                    if (nvalid[j] + 1 <= NP) continue;
+                    const int b0 = boff[j], m = boff[j + 1] - b0;
+                    gp1d_band<W, kGp1dLongNP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; },
+                                              m, LG,
+                                              [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, kGp1dLongNP, double*>(x, nn, LG, Kg, fv, gv); },
+                                              orow + 4 * j, st ? st + j : nullptr);
+                    __syncthreads();
+                }
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) gp1d_cross_band(orow, fitted);
         __syncthreads();
@@ -865,15 +886,17 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
 
 template <int NP, int ROWCAP, int T, int WNP, int MW>
 int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
-                     int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
+                     int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket,
+                     double* kslab = nullptr) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp1d_kernel<NP, ROWCAP, T, WNP, MW>, T, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (kslab && grid > kGp1dLongGrid) grid = kGp1dLongGrid;        // one slab of global scratch per workgroup
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
     hipLaunchKernelGGL((gp1d_kernel<NP, ROWCAP, T, WNP, MW>), dim3((unsigned)grid), dim3(T), 0, stream, B, bins, bin, nan_from, out, ld,
-                       col0, status, st_ld, st0, ticket);
+                       col0, status, st_ld, st0, ticket, kslab);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -882,7 +905,7 @@ int launch_gp1d_tier(const BatchView& B, const Bins& bins, int bin, int nan_from
 // object; bins 3..5 (160..767 rows) with the 160-row matrix -- a band with more than 159 valid points
 // gets NaN and status -100.
 int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
-                int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
+                int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, double* kslab) {
     const int caps[6] = {63, 111, 159, kGpSmallNP - 1, kGpMidNP - 1, kGpGlobalNP - 1};
     int last = 0;
     while (last < 5 && caps[last] < max_len) ++last;
@@ -894,7 +917,7 @@ int launch_gp1d(const BatchView& B, const Bins& bins, int64_t max_len, double* o
             case 0: rc = launch_gp1d_tier<64, 64, kGp1dThreads, 32, 3>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
             case 1: rc = launch_gp1d_tier<112, 112, kGp1dThreads, 32, 2>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
             case 2: rc = launch_gp1d_tier<160, 160, kGp1dThreads, 64, 1>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
-            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads, 64, 1>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk); break;
+            default: rc = launch_gp1d_tier<160, 768, kGp1dThreads, 64, 1>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk, kslab); break;
         }
         if (rc) return rc;
         ++*n_launch;
@@ -990,12 +1013,23 @@ int launch_bazin_partition(const BatchView& B, const Bins& bins, int bin, int na
     return 0;
 }
 
+// tuning knob: LCFE_FIT_WAVES_<rows>=k caps the fit kernels of that band-length tier at k wavefronts per CU (their LDS
+// regions otherwise take most of a CU and keep the LDS-resident GP tiers off it)
+static int fit_waves_cap(int bcap, int per_cu) {
+    char name[40];
+    snprintf(name, sizeof name, "LCFE_FIT_WAVES_%d", bcap);
+    const char* e = getenv(name);
+    if (e && atoi(e) > 0 && atoi(e) < per_cu) return atoi(e);
+    return per_cu;
+}
+
 template <int BCAP>
 int launch_bazin_fits(const BatchView& B, const Bins& bins, const FitWs& F, int tier, double* out, int ld, int col0, int32_t* status,
                       int st_ld, int st0, hipStream_t stream, int dev, unsigned long long* ticket) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bazin_fit_kernel<BCAP>, 64, 0));
     if (per_cu < 1) per_cu = 1;
+    per_cu = fit_waves_cap(BCAP, per_cu);
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (grid * 8 > 6 * B.n_obj) grid = (6 * B.n_obj + 7) / 8;
     if (grid < 1) return 0;
@@ -1080,6 +1114,7 @@ int launch_powerlaw_fits(const BatchView& B, const Bins& bins, const PlWs& F, in
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (powerlaw_fit_kernel<N, BCAP>), 64, 0));
     if (per_cu < 1) per_cu = 1;
+    per_cu = fit_waves_cap(BCAP, per_cu);
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     const int64_t nfit = ((N == 2) ? 21 : 6) * B.n_obj;
     if (grid * 8 > nfit) grid = (nfit + 7) / 8;
@@ -1314,6 +1349,7 @@ size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points) {
     if (mask & (1 << SET_GP2D)) b += kGpScratchBytes;
     if (mask & (1 << SET_BAZIN)) b += bazin_ws_bytes(n_obj, n_points);
     if (mask & (1 << SET_POWERLAW)) b += powerlaw_ws_bytes(n_obj, n_points);
+    if (mask & (1 << SET_GP1D)) b += kGp1dLongBytes;
     return b;
 }
 
@@ -1362,6 +1398,8 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     region += bazin_bytes;
     void* pl_ws = (mask & (1 << SET_POWERLAW)) ? (void*)region : nullptr;
     const size_t pl_bytes = pl_ws ? powerlaw_ws_bytes(n_obj, n_points) : 0;
+    region += pl_bytes;
+    double* gp1d_slab = (mask & (1 << SET_GP1D)) ? (double*)region : nullptr;
     const Bins bins{lists, counts, n_obj};
     // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
     // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
@@ -1435,7 +1473,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
             case SET_RESEARCH: rc = launch_set<SET_RESEARCH>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
-            case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, gp1d_slab); break;
             case SET_GP2D:
                 if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }
                 rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, fork ? side[2] : q, dev, gp_scratch,

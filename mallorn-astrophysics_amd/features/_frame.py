@@ -27,7 +27,7 @@ def _extract_and_warn(set_name, csr, z, kept):
         over = np.flatnonzero(n > lib.lcfe_max_points())
     if over.size:
         limit = SET_LIMITS.get(set_name, int(lib.lcfe_max_points()))
-        what = "a band longer than 159 valid points or more than 767 rows" if set_name == "gp1d" else f"more than {limit} rows"
+        what = "a band longer than 767 valid points or more than 767 rows" if set_name == "gp1d" else f"more than {limit} rows"
         warnings.warn(f"lcfe[{set_name}]: {over.size} object(s) with {what} are beyond the largest kernel tier and "
                       f"got NaN (status -100), e.g. {[kept[i] for i in over[:5]]}", RuntimeWarning, stacklevel=3)
     return out
