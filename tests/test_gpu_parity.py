@@ -455,3 +455,17 @@ def test_bazin_long_light_curves_vs_oracle():
     rel = np.abs(got[:2] - ref)[both] / np.maximum(np.abs(ref[both]), 1e-9)
     assert (rel <= 1e-4).mean() >= 0.9, (rel <= 1e-4).mean()
     assert (st[:2, 0::2] > 0).all()
+
+
+def test_all_ten_sets_in_one_call_equal_the_single_set_calls(golden_inputs):
+    """One call with every feature set (all workspace regions in use at once: GP scratch slabs, Bazin and decline fit
+    lists, the per-band GP's slab) must give, column block by column block, what the single-set calls give."""
+    names = list(SET_NAMES)
+    both = extract_csr(names, golden_inputs, z=golden_inputs["z"])
+    col = 0
+    for name in names:
+        one = extract_csr(name, golden_inputs, z=golden_inputs["z"])
+        blk = both[:, col:col + one.shape[1]]
+        col += one.shape[1]
+        assert np.array_equal(np.nan_to_num(blk, nan=-7.0), np.nan_to_num(one, nan=-7.0)), name
+    assert col == both.shape[1] == sum(len(COLUMNS[n]) for n in names)
