@@ -1078,7 +1078,9 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
     if (rc) return rc;
     *n_launch += 4;
     // objects with a band of more than 256 rows: the object-level kernel (all 52 columns)
-    rc = launch_tier<SET_BAZIN, 1024>(B, bins, kBazinFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5);
+    // (a small grid: the list is normally empty, and every workgroup of this kernel needs 136 KiB of LDS -- a chip-wide
+    // grid would sit in the dispatcher until the GP tiers release whole CUs, holding up the rest of this stream)
+    rc = launch_tier<SET_BAZIN, 1024>(B, bins, kBazinFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
     if (rc) return rc;
     ++*n_launch;
     hipLaunchKernelGGL(bazin_cross_kernel, dim3((unsigned)((B.n_obj + 255) / 256)), dim3(256), 0, stream, B, out, ld, col0);
@@ -1166,7 +1168,7 @@ int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, doubl
 #undef PL_TIER
     if (rc) return rc;
     *n_launch += 8;
-    rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5);
+    rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
     if (rc) return rc;
     ++*n_launch;
     return 0;
