@@ -55,11 +55,35 @@ template <int NP> struct GpFusePanels<NP, true> {
     double P2[GP_B][GP_B];
 };
 
+LCFE_FN double gp_wavelength(int band) {
+    // multiband_gp.py:26-29
+    const double w[6] = {3670.0, 4825.0, 6222.0, 7545.0, 8691.0, 9710.0};
+    return w[band];
+}
+
+// wavelength per valid point and the scratch vector of the flux-scale median.  Plain arrays by default; the fused
+// tiers keep the band code (one byte) instead of the wavelength and borrow the first pivot panel as scratch -- with
+// their second panel that is what lets a 511-row light curve fit the 160 KiB of LDS.
+template <int NP, int LDV, bool SLIM> struct GpSmallArrays {
+    double lam[NP];
+    double r[NP];
+    LCFE_FN double lam_at(int i) const { return lam[i]; }
+    LCFE_FN void set_band(int i, int band) { lam[i] = gp_wavelength(band); }
+    LCFE_FN double* rbuf(double (*)[LDV]) { return r; }
+};
+template <int NP, int LDV> struct GpSmallArrays<NP, LDV, true> {
+    unsigned char bnd[NP];
+    LCFE_FN double lam_at(int i) const { const int b = bnd[i]; return gp_wavelength((b < 6) ? b : 0); }   // rows beyond the points hold stale bytes
+    LCFE_FN void set_band(int i, int band) { bnd[i] = (unsigned char)band; }
+    LCFE_FN double* rbuf(double (*V)[LDV]) { return &V[0][0]; }
+};
+
 template <int NP, int NW = 4, bool FUSE = false>
 struct GpLds {
     static constexpr bool kFuse = FUSE;
-    double t[NP], lam[NP], y[NP], e2[NP];     // valid points: time (from first valid), wavelength, flux/scale, (err/scale)^2
-    double r[NP], alpha[NP];                  // residual y - mu ; K^-1 r
+    double t[NP], y[NP], e2[NP];              // valid points: time (from first valid), flux/scale, (err/scale)^2
+    double alpha[NP];                         // K^-1 r
+    GpSmallArrays<NP, gp_panel_ld(NP), FUSE> sm;
     double V[GP_B][gp_panel_ld(NP)];          // pivot-tile columns A(:, P) (rows p >= bs of a partial block are zero)
     double P[GP_B][GP_B];                     // inverse of the (identity-padded) pivot block
     GpFusePanels<NP, FUSE> fz;
@@ -81,11 +105,6 @@ struct GpLds {
 #define GP_T(slot_) do {} while (0)
 #endif
 
-LCFE_FN double gp_wavelength(int band) {
-    // multiband_gp.py:26-29
-    const double w[6] = {3670.0, 4825.0, 6222.0, 7545.0, 8691.0, 9710.0};
-    return w[band];
-}
 
 #if defined(__HIPCC__)
 typedef double gp_v4f64 __attribute__((ext_vector_type(4)));
@@ -609,11 +628,11 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = (i << 4) + lr + 4 * v;
-                ti[v] = S.t[r]; li[v] = S.lam[r]; ni[v] = S.e2[r] + GP_TINY;
+                ti[v] = S.t[r]; li[v] = S.sm.lam_at(r); ni[v] = S.e2[r] + GP_TINY;
             }
             for (int j = 0; j <= i; ++j) {
                 const int cj = (j << 4) + lc;
-                const double tj = S.t[cj], lj = S.lam[cj], rj = S.y[cj] - mu;
+                const double tj = S.t[cj], lj = S.sm.lam_at(cj), rj = S.y[cj] - mu;
                 KP T = K + tile_base(i, j);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -632,9 +651,9 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
 #endif
     {
     for (int i = rl; i < n; i += RG) {
-        const double ti = S.t[i], li = S.lam[i];
+        const double ti = S.t[i], li = S.sm.lam_at(i);
         for (int j = cl; j <= i; j += G) {
-            const double dt = ti - S.t[j], dl = li - S.lam[j];
+            const double dt = ti - S.t[j], dl = li - S.sm.lam_at(j);
             double e;
             double k = gp_kernel(dt * dt, dl * dl, c, m0, m1, e);
             if (j == i) k += S.e2[i] + GP_TINY;
@@ -678,11 +697,11 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = (i << 4) + lr + 4 * v;
-                ti[v] = S.t[r]; li[v] = S.lam[r]; ai[v] = S.alpha[r];
+                ti[v] = S.t[r]; li[v] = S.sm.lam_at(r); ai[v] = S.alpha[r];
             }
             for (int j = 0; j <= i; ++j) {
                 const int cj = (j << 4) + lc;
-                const double tj = S.t[cj], lj = S.lam[cj], aj = S.alpha[cj];
+                const double tj = S.t[cj], lj = S.sm.lam_at(cj), aj = S.alpha[cj];
                 KP T = K + tile_base(i, j);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -704,9 +723,9 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
     } else
 #endif
     for (int i = rl; i < n; i += RG) {
-        const double ai = S.alpha[i], ti = S.t[i], li = S.lam[i];
+        const double ai = S.alpha[i], ti = S.t[i], li = S.sm.lam_at(i);
         for (int j = cl; j <= i; j += G) {
-            const double dt = ti - S.t[j], dl = li - S.lam[j];
+            const double dt = ti - S.t[j], dl = li - S.sm.lam_at(j);
             const double dt2 = dt * dt, dl2 = dl * dl;
             double e;
             const double k = gp_kernel(dt2, dl2, c, m0, m1, e);
@@ -760,7 +779,7 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
             int pos = 0;
             for (int j = 0; j < i; ++j) pos += gp_row_valid(L, j) ? 1 : 0;
             S.t[pos] = L.t[i];
-            S.lam[pos] = gp_wavelength(L.b[i]);
+            S.sm.set_band(pos, L.b[i]);
             S.y[pos] = L.f[i];
             S.e2[pos] = L.e[i];
         }
@@ -775,17 +794,18 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
     for (int i = lane; i < n; i += W::LANES) { tmin = fmin(tmin, S.t[i]); }
     tmin = W::min(tmin);
     // flux_scale = median(|f| over f != 0) (:78-80): zeros are parked at +inf so that the non-zero
-    // values occupy ranks 0..nnz-1 (r[] is scratch here)
+    // values occupy ranks 0..nnz-1 (scratch vector: see GpSmallArrays)
+    double* rscr = S.sm.rbuf(S.V);
     for (int i = lane; i < n; i += W::LANES) {
         const bool nz = (S.y[i] != 0.0);
-        S.r[i] = nz ? fabs(S.y[i]) : __builtin_inf();
+        rscr[i] = nz ? fabs(S.y[i]) : __builtin_inf();
         nnz += nz ? 1 : 0;
     }
     nnz = W::sum(nnz);
     W::sync();
     double scale = qnan();
     if (nnz > 0) {
-        wave_rank_select<W>(S.r, n, (nnz - 1) / 2, nnz / 2, S.slot, reinterpret_cast<unsigned long long*>(S.alpha));
+        wave_rank_select<W>(rscr, n, (nnz - 1) / 2, nnz / 2, S.slot, reinterpret_cast<unsigned long long*>(S.alpha));
         scale = ((nnz & 1) ? S.slot[0] : (S.slot[0] + S.slot[1]) / 2.0);
         W::sync();
     }
@@ -874,7 +894,7 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
         const double tp = peak_time + EP[q / 3], lp = gp_wavelength(PB[q % 3]);
         double s = 0;
         for (int i = lane; i < n; i += W::LANES) {
-            const double dt = tp - S.t[i], dl = lp - S.lam[i];
+            const double dt = tp - S.t[i], dl = lp - S.sm.lam_at(i);
             double e;
             s += gp_kernel(dt * dt, dl * dl, c, m0, m1, e) * S.alpha[i];
         }

@@ -84,8 +84,8 @@ __device__ __forceinline__ int set_bin_of(int64_t n) {
     return (n <= 128) ? 0 : (n <= 256) ? 1 : (n <= 512) ? 2 : (n <= 1024) ? 3 : (n <= 2048) ? 4 : 6;
 }
 constexpr int kGpSmallNP = 240;     // matrix in global scratch, two pivot tiles per pass, two 512-thread workgroups per CU
-constexpr int kGpMidNP = 480;       // matrix in global scratch, two pivot tiles per pass, one 1024-thread workgroup per CU
-constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one pivot tile per pass (480..767 rows)
+constexpr int kGpMidNP = 512;       // matrix in global scratch, two pivot tiles per pass, one 512-thread workgroup per CU
+constexpr int kGpGlobalNP = 768;    // matrix in global scratch, one pivot tile per pass (512..767 rows)
 // GP window on the ROW count of the object (>= its valid points); one row of the tile storage is the
 // augmented residual row, so the caps are NP - 1.
 __device__ __forceinline__ int gp_bin_of(int64_t n) {
@@ -618,12 +618,12 @@ constexpr size_t kGpScratchBytes = kGpSmallBytes + kGpMidBytes + kGpGlobalBytes 
 
 template <int NP> struct gp_threads { static constexpr int T = (NP >= 768) ? 1024 : ((NP >= 160) ? 512 : 256); };
 // the two global-scratch tiers whose second pivot panel fits LDS sweep two pivot tiles per pass over the matrix
-template <int NP, bool GLOBAL_K> struct gp_fuse { static constexpr bool F = GLOBAL_K && NP <= 480; };
+template <int NP, bool GLOBAL_K> struct gp_fuse { static constexpr bool F = GLOBAL_K && NP <= 512; };
 template <int NP> struct gp_grid_cap { static constexpr int G = (NP == 112) ? kGp112Grid : ((NP == 160) ? kGp160Grid : ((NP == kGpSmallNP) ? kGpSmallGrid : kGpGlobalGrid)); };
 
 // waves per SIMD to leave room for: the 64- and 112-row tiers fit two or more workgroups per CU in LDS,
 // so their register budget is halved (the L-BFGS-B driver spills a little, the sweep does not)
-template <int NP, bool GLOBAL_K> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : (GLOBAL_K ? ((NP == 480) ? 2 : 4) : 2); };
+template <int NP, bool GLOBAL_K> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : (GLOBAL_K ? ((NP == 512) ? 2 : 4) : 2); };
 
 template <int NP, bool GLOBAL_K>
 __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
