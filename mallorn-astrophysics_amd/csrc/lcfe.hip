@@ -18,6 +18,7 @@
 #include "../../include/lcfe.h"
 #include "feature_sets.hpp"
 #include "stat_lean.hpp"
+#include "stat_lanes.hpp"
 #include "gp1d.hpp"
 
 using namespace lcfe;
@@ -263,6 +264,28 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
     }
     LCFE_PT(5);
     LCFE_PT_FLUSH();
+}
+
+// Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp): CAP = rows of u, g, z, y a
+// lane holds (r and i: 2 CAP over two lanes).  One ticket = eight consecutive list entries.  Light curves that do not
+// fit the shape are appended to the general kernel's list.
+template <int CAP>
+__global__ __launch_bounds__(64, (CAP <= 32) ? 2 : 1) void stat_lanes_kernel(BatchView B, Bins bins, int bin, double* out, int ld,
+                                                                            int col0, unsigned long long* ticket) {
+    __shared__ StatLanesLds<CAP> L;
+    __shared__ long long next_ticket;
+    const int count = bins.counts[bin];
+    const int* list = bins.lists + (int64_t)bin * bins.stride;
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t base = next_ticket * 8;
+        __syncthreads();
+        if (base >= count) break;
+        const int nk = (count - base < 8) ? (int)(count - base) : 8;
+        stat_lanes_batch<CAP>(B.offsets, B.t, B.f, B.e, B.b, list + base, nk, L, out, ld, col0,
+                              bins.lists + (int64_t)kStatFallbackList * bins.stride, &bins.counts[kStatFallbackList]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1189,6 +1212,27 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
     return 0;
 }
 
+template <int CAP>
+int launch_stat_lanes(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
+                      int dev, unsigned long long* ticket) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stat_lanes_kernel<CAP>, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL((stat_lanes_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0, ticket);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// LCFE_STAT_LANES=1 runs the 128- and 256-row tiers on the eight-light-curves-per-wavefront kernels (work in progress:
+// correct, not yet faster than the one-light-curve-per-wavefront kernels)
+static bool stat_lanes_enabled() {
+    const char* e = getenv("LCFE_STAT_LANES");
+    return e && e[0] == '1';
+}
+
 // Statistics: lean kernels for the tiers up to 512 rows, the general kernel for the longer tiers,
 // for the lean kernels' fallback list and for the NaN rows of over-long objects.
 int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0,
@@ -1199,6 +1243,7 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     // the tier kernels are independent (disjoint objects): with side streams they are enqueued side by side, so the
     // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch
     const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
+    const bool lanes = stat_lanes_enabled();
     hipEvent_t ev_fork = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
     struct Cleanup { hipEvent_t* e[3]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_j1, &ev_j2}};
     if (fork) {
@@ -1212,8 +1257,10 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         hipStream_t q = !fork ? stream : ((ti % 3 == 0) ? stream : ((ti % 3 == 1) ? s1 : s2));
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
-            case 1: rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 0: rc = lanes ? launch_stat_lanes<32>(B, bins, ti, out, ld, col0, q, dev, tk + ti)
+                               : launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 1: rc = lanes ? launch_stat_lanes<64>(B, bins, ti, out, ld, col0, q, dev, tk + ti)
+                               : launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
             case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
             case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
             case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
