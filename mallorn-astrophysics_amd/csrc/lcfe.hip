@@ -71,10 +71,11 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 3;
+constexpr int kNumLists = 2 * kNumBins + 5;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
+constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light curves the lanes kernel of the tier could not take
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -268,24 +269,13 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
 
 // Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp): CAP = rows of u, g, z, y a
 // lane holds (r and i: 2 CAP over two lanes).  One ticket = eight consecutive list entries.  Light curves that do not
-// fit the shape are appended to the general kernel's list.
+// fit the shape are appended to the tier's retry list, which the one-light-curve-per-wavefront kernel of the tier takes.
 template <int CAP>
 __global__ __launch_bounds__(64, (CAP <= 32) ? 2 : 1) void stat_lanes_kernel(BatchView B, Bins bins, int bin, double* out, int ld,
-                                                                            int col0, unsigned long long* ticket) {
+                                                                            int col0) {
     __shared__ StatLanesLds<CAP> L;
-    __shared__ long long next_ticket;
-    const int count = bins.counts[bin];
-    const int* list = bins.lists + (int64_t)bin * bins.stride;
-    for (;;) {
-        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
-        __syncthreads();
-        const int64_t base = next_ticket * 8;
-        __syncthreads();
-        if (base >= count) break;
-        const int nk = (count - base < 8) ? (int)(count - base) : 8;
-        stat_lanes_batch<CAP>(B.offsets, B.t, B.f, B.e, B.b, list + base, nk, L, out, ld, col0,
-                              bins.lists + (int64_t)kStatFallbackList * bins.stride, &bins.counts[kStatFallbackList]);
-    }
+    stat_lanes_run<CAP, CAP / 2>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)bin * bins.stride, bins.counts[bin], L, out, ld,
+                                 col0, bins.lists + (int64_t)(kStatRetryList + bin) * bins.stride, &bins.counts[kStatRetryList + bin]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1199,11 +1189,12 @@ int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, doubl
 
 template <int CAP>
 int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
-                     int dev, unsigned long long* ticket) {
+                     int dev, unsigned long long* ticket, int64_t grid_cap = 0) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stat_lean_kernel<CAP>, 64, 0));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;    // a list expected to be short: every wavefront's first ticket is an atomic on one counter
     if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
     if (grid < 1) return 0;
     hipLaunchKernelGGL((stat_lean_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0,
@@ -1215,22 +1206,21 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
 template <int CAP>
 int launch_stat_lanes(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
                       int dev, unsigned long long* ticket) {
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stat_lanes_kernel<CAP>, 64, 0));
-    if (per_cu < 1) per_cu = 1;
-    int64_t grid = (int64_t)num_cus(dev) * per_cu;
-    if (grid * 8 > B.n_obj) grid = (B.n_obj + 7) / 8;
+    // one workgroup per batch of eight list entries; the list length is known on the device only, so the grid covers
+    // the whole batch and the workgroups behind the list's end leave at once
+    const int64_t grid = (B.n_obj + 7) / 8;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((stat_lanes_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0, ticket);
+    hipLaunchKernelGGL((stat_lanes_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// LCFE_STAT_LANES=1 runs the 128- and 256-row tiers on the eight-light-curves-per-wavefront kernels (work in progress:
-// correct, not yet faster than the one-light-curve-per-wavefront kernels)
+// LCFE_STAT_LANES=0 keeps the one-light-curve-per-wavefront kernel for the 128-row tier (A/B measurements);
+// LCFE_STAT_LANES64=1 also runs the 256-row tier eight light curves per wavefront (one wavefront per SIMD at that
+// register count: slower than stat_lean_kernel<256> as measured)
 static bool stat_lanes_enabled() {
     const char* e = getenv("LCFE_STAT_LANES");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }
 
 // Statistics: lean kernels for the tiers up to 512 rows, the general kernel for the longer tiers,
@@ -1244,6 +1234,7 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch
     const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
     const bool lanes = stat_lanes_enabled();
+    const bool lanes64 = getenv("LCFE_STAT_LANES64") != nullptr;
     hipEvent_t ev_fork = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
     struct Cleanup { hipEvent_t* e[3]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_j1, &ev_j2}};
     if (fork) {
@@ -1257,10 +1248,22 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         hipStream_t q = !fork ? stream : ((ti % 3 == 0) ? stream : ((ti % 3 == 1) ? s1 : s2));
         int rc = 0;
         switch (ti) {
-            case 0: rc = lanes ? launch_stat_lanes<32>(B, bins, ti, out, ld, col0, q, dev, tk + ti)
-                               : launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
-            case 1: rc = lanes ? launch_stat_lanes<64>(B, bins, ti, out, ld, col0, q, dev, tk + ti)
-                               : launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
+            case 0:
+                if (lanes) {
+                    rc = launch_stat_lanes<32>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
+                    if (!rc) rc = launch_stat_lean<128>(B, bins, kStatRetryList + 0, out, ld, col0, q, dev, tk + 6, 512);
+                } else {
+                    rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
+                }
+                break;
+            case 1:
+                if (lanes && lanes64) {
+                    rc = launch_stat_lanes<64>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
+                    if (!rc) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q, dev, tk + 7, 512);
+                } else {
+                    rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
+                }
+                break;
             case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
             case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
             case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;

@@ -162,230 +162,202 @@ __device__ __forceinline__ void lanes_order_stats(const double* buf, int base, i
 __device__ __forceinline__ double lanes_pair(double x) { return lane_xor_fetch<1>(x); }
 __device__ __forceinline__ int lanes_pair(int x) { return lane_xor_fetch<1>(x); }
 
-// Eight light curves (list entries list[0..nk)) -> their 123 columns, or the general kernel's list.
-template <int CAP>
-__device__ __forceinline__ void stat_lanes_batch(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
-                                                 const uint8_t* gb, const int* list, int nk, StatLanesLds<CAP>& L,
-                                                 double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
+// Eight light curves (one per 8-lane group: `obj` < 0 = none; CSR rows [s1, e1)) -> their 123 columns, or the general
+// kernel's list.  ITERS = rows / 8 a light curve of the tier may have.  Lane j of a group holds rows j, j + 8, ... of its
+// light curve (t, f, e, band code; 256 = no row -- 255 is a band code a file may hold) in registers from ONE round of
+// loads.  Not inlined: the caller's loop state stays out of this function's register budget.
+template <int CAP, int ITERS>
+__device__ __forceinline__ void stat_lanes_batch(const double* gt, const double* gf, const double* ge, const uint8_t* gb, int obj,
+                                              int64_t s1, int64_t e1, double* buf, double* out, int ld, int col0,
+                                              int* fallback_list, int* fallback_count) {
     using G = GroupDev<8>;
     constexpr int STRIDE = StatLanesLds<CAP>::STRIDE;
-    constexpr int BLK = 4;                                  // rows of a light curve per lane between two waits on memory
-    double* buf = L.buf;
+    constexpr int BLK = 4;
+    static_assert(ITERS % BLK == 0 && ITERS <= CAP, "rows per lane");
     const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7, g8 = g << 3;
-    int obj = -1, n = 0;
-    int64_t s0 = 0;
-    if (g < nk) {
-        obj = list[g];
-        s0 = offsets[obj];
-        n = (int)(offsets[obj + 1] - s0);
-    }
-    const double *pt = gt + s0, *pf = gf + s0, *pe = ge + s0;
-    const uint8_t* pb = gb + s0;
+    (void)g;
+    const int n = (int)(e1 - s1);
+    const bool has_obj = obj >= 0;
+    bool fit = has_obj && n >= 1 && n <= 8 * ITERS;
+    const int nr = fit ? n : 0;
     int nmax = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int nk_ = __builtin_amdgcn_readlane(n, 8 * k); nmax = (nk_ > nmax) ? nk_ : nmax; }
-    bool fit = n >= 1 && n <= 8 * CAP;
-    const int nr = fit ? n : 0;                             // rows this group stages
-    nmax = (nmax < 8 * CAP) ? nmax : 8 * CAP;
+    for (int k = 0; k < 8; ++k) { const int v_ = __builtin_amdgcn_readlane(nr, 8 * k); nmax = (v_ > nmax) ? v_ : nmax; }
     const int iters = (nmax + 7) >> 3;
+    // ---- rows -> registers
+    double rt[ITERS], rf[ITERS], rq[ITERS];
+    int code[ITERS];
+    {
+        const double *pt = gt + s1, *pf = gf + s1, *pe = ge + s1;
+        const uint8_t* pb = gb + s1;
+#pragma unroll
+        for (int i0 = 0; i0 < ITERS; i0 += BLK) {
+            if (i0 < iters) {
+#pragma unroll
+                for (int q = 0; q < BLK; ++q) {
+                    const int row = (i0 + q) * 8 + j;
+                    const bool ok = row < nr;
+                    code[i0 + q] = ok ? (int)pb[row] : 256;
+                    rt[i0 + q] = ok ? pt[row] : 0.0;
+                    rf[i0 + q] = ok ? pf[row] : 0.0;
+                    rq[i0 + q] = ok ? pe[row] : 0.0;
+                }
+            }
+        }
+    }
 
-    // ---- A: slot of every row inside its band
-    int code[CAP];
+    // ---- A: slot of every row inside its band = rows of that band before it (ballots over the 8 rows of a trip)
     int cnt[6] = {0, 0, 0, 0, 0, 0};
     bool known = true;
 #pragma unroll
-    for (int i0 = 0; i0 < CAP; i0 += BLK) {
-        if (i0 < iters) {
-            int bb[BLK];
+    for (int it = 0; it < ITERS; ++it) {
+        if ((it & ~(BLK - 1)) < iters) {
+            const int b = code[it];
+            known = known && (b < 6 || b == 256);
+            unsigned int mine = 0;
+            int c0 = 0;
 #pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int row = (i0 + q) * 8 + j;
-                bb[q] = (row < nr) ? (int)pb[row] : 256;            // 256 = no row (255 is a band code a file may hold)
+            for (int k = 0; k < 6; ++k) {
+                const unsigned int m8 = (unsigned int)(__ballot(b == k) >> g8) & 0xFFu;
+                if (b == k) { mine = m8; c0 = cnt[k]; }
+                cnt[k] += __builtin_popcount(m8);
             }
-#pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int b = bb[q];
-                known = known && (b < 6 || b == 256);
-                unsigned int mine = 0;
-                int c0 = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const unsigned int m8 = (unsigned int)(__ballot(b == k) >> g8) & 0xFFu;
-                    if (b == k) { mine = m8; c0 = cnt[k]; }
-                    cnt[k] += __builtin_popcount(m8);
-                }
-                const int pos = c0 + __builtin_popcount(mine & ((1u << j) - 1u));
-                code[i0 + q] = ((b < 6) ? b : 7) | (pos << 8);
-            }
+            const int pos = c0 + __builtin_popcount(mine & ((1u << j) - 1u));
+            code[it] = ((b < 6) ? b : 7) | (pos << 8);
         }
     }
     fit = fit && G::all(known) && cnt[0] <= CAP && cnt[1] <= CAP && cnt[4] <= CAP && cnt[5] <= CAP && cnt[2] <= 2 * CAP &&
           cnt[3] <= 2 * CAP;
     const int N = fit ? n : 0;
     const int h1r = (cnt[2] + 1) >> 1, h1i = (cnt[3] + 1) >> 1;
-    // this lane's share: band, rows, neighbour pairs
+    // this lane's share: band, rows
     const int band = (j == 0) ? 0 : (j == 1) ? 1 : (j <= 3) ? 2 : (j == 4) ? 4 : (j == 5) ? 5 : 3;
     const bool split = (j & 2) != 0, first = split && (j & 1) == 0;
     int mband = (band == 0) ? cnt[0] : (band == 1) ? cnt[1] : (band == 2) ? cnt[2] : (band == 3) ? cnt[3] : (band == 4) ? cnt[4] : cnt[5];
     const int h1 = (band == 2) ? h1r : h1i;
     int m = !split ? mband : (first ? h1 : mband - h1);
     if (!fit) { m = 0; mband = 0; }
-    const int npairs = m - 1 + ((first && mband > m) ? 1 : 0);     // a first half sees the first row of the second one at slot m
+    const bool bridge = first && mband > m;                 // the pair (last row of the first half, first row of the second)
     const int col = lane * STRIDE;
-    // destination of every row: low half = slot address, high half = address of its copy at the end of a first half
+
+    // ---- per row: LDS slot (-1: none); the all-rows slope and the order check from the file neighbours (row + 1 = next
+    //      lane, or lane 0 of the next trip); the SNR term in place of the error (-0.0 = error bar not positive: the
+    //      reference leaves the row out; a term is never negative)
+    bool ordered = true, a_snan = false;
+    double a_slope = -1.0;
 #pragma unroll
-    for (int it = 0; it < CAP; ++it) {
-        if ((it & ~(BLK - 1)) < iters) {                       // every trip of a started block of rows
+    for (int it = 0; it < ITERS; ++it) {
+        if ((it & ~(BLK - 1)) < iters) {
             const int b = code[it] & 0xFF, pos = code[it] >> 8;
             const bool second = (b == 2 && pos >= h1r) || (b == 3 && pos >= h1i);
             const int hb = (b == 2) ? h1r : h1i;
             const int dl = (b == 0) ? 0 : (b == 1) ? 1 : (b == 2) ? 2 : (b == 3) ? 6 : (b == 4) ? 4 : 5;
-            const int slot = second ? pos - hb : pos;
-            const int dest = (g8 + dl + (second ? 1 : 0)) * STRIDE + slot;
-            const int sent = (second && slot == 0) ? dest - STRIDE + hb : 0xFFFF;
-            code[it] = (b < 6 && fit) ? (dest | (sent << 16)) : -1;
+            code[it] = (b < 6 && fit) ? (g8 + dl + (second ? 1 : 0)) * STRIDE + (second ? pos - hb : pos) : -1;
+            const int row = it * 8 + j;
+            const bool has = row + 1 < N;
+            const double tn_l = G::template dpp<0x101>(rt[it]), fn_l = G::template dpp<0x101>(rf[it]);   // row_shl:1
+            const double tn_w = G::template dpp<0x117>(rt[(it + 1 < ITERS) ? it + 1 : it]),              // row_shr:7
+                         fn_w = G::template dpp<0x117>(rf[(it + 1 < ITERS) ? it + 1 : it]);
+            const double t1 = (j == 7) ? tn_w : tn_l, f1 = (j == 7) ? fn_w : fn_l;
+            ordered = ordered && !(has && !(rt[it] <= t1));
+            const double dt = t1 - rt[it];
+            const double sl = fabs((f1 - rf[it]) / dt);
+            const bool valid = has && dt > 0;
+            a_snan = a_snan || (valid && is_nan(sl));
+            a_slope = (valid && sl > a_slope) ? sl : a_slope;
+            rq[it] = (rq[it] > 0) ? fabs(rf[it]) / rq[it] : -0.0;
         }
     }
 
-    // ---- F: fluxes
+    // ---- F: fluxes -> lanes (the columns are cleared first: the slots behind a lane's rows read as 0.0 in every phase)
 #pragma unroll
-    for (int i0 = 0; i0 < CAP; i0 += BLK) {
-        if (i0 < iters) {
-            double x[BLK];
+    for (int i = 0; i < STRIDE; ++i) buf[col + i] = 0.0;
+    G::sync();
 #pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int row = (i0 + q) * 8 + j;
-                x[q] = (row < N) ? pf[row] : 0.0;
-            }
+    for (int it = 0; it < ITERS; ++it)
+        if ((it & ~(BLK - 1)) < iters && code[it] >= 0) buf[code[it]] = rf[it];
+    G::sync();
+    double v[CAP];
 #pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int c = code[i0 + q];
-                if (c != -1) {
-                    buf[c & 0xFFFF] = x[q];
-                    if (((c >> 16) & 0xFFFF) != 0xFFFF) buf[(c >> 16) & 0xFFFF] = x[q];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    double v[CAP + 1];
-#pragma unroll
-    for (int i = 0; i <= CAP; ++i) v[i] = buf[col + i];
-    double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+    for (int i = 0; i < CAP; ++i) v[i] = buf[col + i];
+    const double f_last = buf[col + ((m > 0) ? m - 1 : 0)], f_next = buf[col + STRIDE - ((j == 7) ? STRIDE : 0)];
+    double s;
     bool nanf = false;
+    {
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) {
-        const bool ok = i < m;
-        const double x = v[i];
-        s += ok ? x : 0.0;
-        nanf = nanf || (ok && is_nan(x));
-        mn = dmin(mn, ok ? x : __builtin_inf());
-        mx = dmax(mx, ok ? x : -__builtin_inf());
-    }
-    __syncthreads();
-
-    // ---- T: times; all-rows slope and the order check from the file neighbours
-    bool ordered = true, a_snan = false;
-    double a_slope = -1.0;
-#pragma unroll
-    for (int i0 = 0; i0 < CAP; i0 += BLK) {
-        if (i0 < iters) {
-            double t0[BLK], t1[BLK], f0[BLK], f1[BLK];
-#pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int row = (i0 + q) * 8 + j;
-                const bool ok0 = row < N, ok1 = row + 1 < N;
-                t0[q] = ok0 ? pt[row] : 0.0;
-                t1[q] = ok1 ? pt[row + 1] : 0.0;
-                f0[q] = ok0 ? pf[row] : 0.0;
-                f1[q] = ok1 ? pf[row + 1] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int row = (i0 + q) * 8 + j;
-                const bool has = row + 1 < N;
-                ordered = ordered && !(has && !(t0[q] <= t1[q]));
-                const double dt = t1[q] - t0[q];
-                const double sl = fabs((f1[q] - f0[q]) / dt);
-                const bool valid = has && dt > 0;
-                a_snan = a_snan || (valid && is_nan(sl));
-                a_slope = (valid && sl > a_slope) ? sl : a_slope;
-                const int c = code[i0 + q];
-                if (c != -1) {
-                    buf[c & 0xFFFF] = t0[q];
-                    if (((c >> 16) & 0xFFFF) != 0xFFFF) buf[(c >> 16) & 0xFFFF] = t0[q];
-                }
-            }
+        for (int i = 0; i < CAP; ++i) {
+            sa[i & 3] += v[i];
+            nanf = nanf || is_nan(v[i]);
         }
+        s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     }
-    __syncthreads();
+    G::sync();
+
+    // ---- T: times -> lanes, band slopes against the register-resident fluxes
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if ((it & ~(BLK - 1)) < iters && code[it] >= 0) buf[code[it]] = rt[it];
+    G::sync();
     double slope = -1.0, tmn, tmx;
     bool snan = false;
     {
         double tc = buf[col];
+        tmn = tc;
 #pragma unroll
-        for (int i = 0; i < CAP; ++i) {
+        for (int i = 0; i + 1 < CAP; ++i) {
             const double tn = buf[col + i + 1];
             const double dt = tn - tc;
             const double sl = fabs((v[i + 1] - v[i]) / dt);
-            const bool valid = i < npairs && dt > 0;
+            const bool valid = i + 1 < m && dt > 0;
             snan = snan || (valid && is_nan(sl));
             slope = (valid && sl > slope) ? sl : slope;
             tc = tn;
         }
-        tmn = buf[col];
         tmx = buf[col + ((m > 0) ? m - 1 : 0)];
-    }
-    __syncthreads();
-
-    // ---- Q: SNR terms (-1 = error bar not positive: the reference leaves the row out)
-#pragma unroll
-    for (int i0 = 0; i0 < CAP; i0 += BLK) {
-        if (i0 < iters) {
-            double x[BLK], e[BLK];
-#pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int row = (i0 + q) * 8 + j;
-                x[q] = (row < N) ? pf[row] : 0.0;
-                e[q] = (row < N) ? pe[row] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < BLK; ++q) {
-                const int c = code[i0 + q];
-                const double qv = (e[q] > 0) ? fabs(x[q]) / e[q] : -1.0;
-                if (c != -1) buf[c & 0xFFFF] = qv;
-            }
+        if (bridge) {
+            const double dt = buf[col + STRIDE] - tmx;
+            const double sl = fabs((f_next - f_last) / dt);
+            const bool valid = dt > 0;
+            snan = snan || (valid && is_nan(sl));
+            slope = (valid && sl > slope) ? sl : slope;
         }
     }
-    __syncthreads();
-    double snr = 0.0;
-    int nsnr = 0;
+    G::sync();
+
+    // ---- Q: SNR terms -> lanes
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) {
-        const double qv = buf[col + i];
-        const bool use = i < m && !(qv < 0);
-        snr += use ? qv : 0.0;
-        nsnr += use ? 1 : 0;
+    for (int it = 0; it < ITERS; ++it)
+        if ((it & ~(BLK - 1)) < iters && code[it] >= 0) buf[code[it]] = rq[it];
+    G::sync();
+    double snr;
+    int nsnr = m;
+    {
+        double qa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {
+            const double qv = buf[col + i];
+            qa[i & 3] += qv;
+            nsnr -= (int)((unsigned long long)__builtin_bit_cast(long long, qv) >> 63);
+        }
+        snr = (qa[0] + qa[1]) + (qa[2] + qa[3]);
     }
-    __syncthreads();
+    G::sync();
 
     // ---- pass-1 totals: per band (the two halves of r and i combined) and over the light curve
     const double sA = G::sum(s), snrA = G::sum(snr);
     const int nsnrA = G::sum(nsnr);
     const bool nanA = G::any(nanf);
-    double mnA = G::min(mn), mxA = G::max(mx);
     const double a_slopeA = G::max(a_slope);
     const bool a_snanA = G::any(a_snan);
     const bool orderedA = G::all(ordered);
-    double tmnA = G::min((m > 0) ? tmn : __builtin_inf()), tmxA = G::max((m > 0) ? tmx : -__builtin_inf());
+    const double tmnA = G::min((m > 0) ? tmn : __builtin_inf()), tmxA = G::max((m > 0) ? tmx : -__builtin_inf());
     if (split) {
+        const int p_nan = lanes_pair(nanf ? 1 : 0), p_snan = lanes_pair(snan ? 1 : 0);   // fetched by every lane (no short-circuit)
         s += lanes_pair(s);
         snr += lanes_pair(snr);
         nsnr += lanes_pair(nsnr);
-        const int p_nan = lanes_pair(nanf ? 1 : 0), p_snan = lanes_pair(snan ? 1 : 0);   // fetched by every lane (no short-circuit)
         nanf = nanf | (p_nan != 0);
-        mn = dmin(mn, lanes_pair(mn));
-        mx = dmax(mx, lanes_pair(mx));
         const double p_tmn = lanes_pair(tmn), p_tmx = lanes_pair(tmx), p_slope = lanes_pair(slope);
         const int p_m = mband - m;
         tmn = first ? tmn : p_tmn;                     // a band with rows has rows in its first half
@@ -393,44 +365,54 @@ __device__ __forceinline__ void stat_lanes_batch(const int64_t* offsets, const d
         slope = (p_slope > slope) ? p_slope : slope;
         snan = snan | (p_snan != 0);
     }
-    if (nanf) { mn = qnan(); mx = qnan(); }
-    if (nanA) { mnA = qnan(); mxA = qnan(); }
     const double mean = s / mband, meanA = sA / N;
 
-    // ---- pass 2
-    double m2 = 0.0, m2A = 0.0;
+    // ---- behind the lane's rows the band mean: the centred band passes need no per-element mask (a padded slot adds
+    //      exactly 0 and counts as "inside"); the all-rows terms are masked
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) {
-        const bool ok = i < m;
-        const double d = v[i] - mean, dA = v[i] - meanA;
-        m2 += ok ? d * d : 0.0;
-        m2A += ok ? dA * dA : 0.0;
+    for (int i = 0; i < CAP; ++i) v[i] = (i < m) ? v[i] : mean;
+    // ---- pass 2
+    double m2, m2A;
+    {
+        double a[2] = {0.0, 0.0}, aA[2] = {0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < CAP; ++i) {
+            const double d = v[i] - mean, dA = (i < m) ? v[i] - meanA : 0.0;
+            a[i & 1] += d * d;
+            aA[i & 1] += dA * dA;
+        }
+        m2 = a[0] + a[1];
+        m2A = aA[0] + aA[1];
     }
     m2A = G::sum(m2A);
     if (split) m2 += lanes_pair(m2);
     const double sd = (mband > 1) ? sqrt(m2 / mband) : 0.0, sdA = (N > 1) ? sqrt(m2A / N) : 0.0;
 
     // ---- pass 3 (the lanes of a light curve whose spread is not positive carry garbage that is dropped below)
-    double s3 = 0.0, s4 = 0.0, s3A = 0.0, s4A = 0.0;
+    double s3, s4, s3A, s4A;
     int c1 = 0, c2 = 0, c1A = 0, c2A = 0;
     {
         const double inv = 1.0 / sd, sd2 = 2.0 * sd, invA = 1.0 / sdA, sdA2 = 2.0 * sdA;
+        double a3[2] = {0.0, 0.0}, a4[2] = {0.0, 0.0}, b3[2] = {0.0, 0.0}, b4[2] = {0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < CAP; ++i) {
-            const bool ok = i < m;
-            const double d = v[i] - mean, dA = v[i] - meanA;
+            const double d = v[i] - mean, dA = (i < m) ? v[i] - meanA : 0.0;
             const double zz = d * inv, zA = dA * invA;
             const double z2 = zz * zz, zA2 = zA * zA;
-            s3 += ok ? z2 * zz : 0.0;
-            s4 += ok ? z2 * z2 : 0.0;
-            s3A += ok ? zA2 * zA : 0.0;
-            s4A += ok ? zA2 * zA2 : 0.0;
+            a3[i & 1] += z2 * zz;
+            a4[i & 1] += z2 * z2;
+            b3[i & 1] += zA2 * zA;
+            b4[i & 1] += zA2 * zA2;
             const double ad = fabs(d), adA = fabs(dA);
-            c1 += (ok && ad > sd) ? 1 : 0;
-            c2 += (ok && ad > sd2) ? 1 : 0;
-            c1A += (ok && adA > sdA) ? 1 : 0;
-            c2A += (ok && adA > sdA2) ? 1 : 0;
+            c1 += (ad > sd) ? 1 : 0;
+            c2 += (ad > sd2) ? 1 : 0;
+            c1A += (adA > sdA) ? 1 : 0;
+            c2A += (adA > sdA2) ? 1 : 0;
         }
+        s3 = a3[0] + a3[1];
+        s4 = a4[0] + a4[1];
+        s3A = b3[0] + b3[1];
+        s4A = b4[0] + b4[1];
     }
     s3A = G::sum(s3A);
     s4A = G::sum(s4A);
@@ -458,33 +440,43 @@ __device__ __forceinline__ void stat_lanes_batch(const int64_t* offsets, const d
     finish(mband, sd, s3, s4, c1, c2, skew, kurt, b1, b2);
     finish(N, sdA, s3A, s4A, c1A, c2A, skewA, kurtA, b1A, b2A);
 
-    // ---- order statistics: register sort per lane, then merges across the lanes
+
+    // ---- order statistics and extrema: register sort per lane, then merges across the lanes
     double w[CAP];
 #pragma unroll
     for (int i = 0; i < CAP; ++i) w[i] = (i < m) ? v[i] : __builtin_inf();
     reg_sort<CAP>(w);
+    double mn = w[0], mx = -__builtin_inf();                // the maximum is read off the dumps (rank rows - 1)
     double med = qnan(), iqr = qnan(), mad = qnan();
 #pragma unroll
     for (int i = 0; i < CAP; ++i) buf[col + i] = w[i];
-    __syncthreads();
+    G::sync();
+    if (m > 0) mx = buf[col + m - 1];
     if (!split && m > 0 && !nanf) lanes_order_stats<CAP>(buf, col, m, med, iqr, mad);
-    __syncthreads();
+    G::sync();
+    double mnA = G::min(mn), mxA = G::max(mx);
+    if (split) {
+        mn = dmin(mn, lanes_pair(mn));
+        mx = dmax(mx, lanes_pair(mx));
+    }
     lane_merge<CAP, 1>(w, j);
 #pragma unroll
     for (int i = 0; i < CAP; ++i) buf[col + i] = w[i];
-    __syncthreads();
+    G::sync();
     if (first && mband > 0 && !nanf) lanes_order_stats<CAP>(buf, col, mband, med, iqr, mad);
-    __syncthreads();
+    G::sync();
     lane_merge<CAP, 2>(w, j);
     lane_merge<CAP, 4>(w, j);
 #pragma unroll
     for (int i = 0; i < CAP; ++i) buf[col + i] = w[i];
-    __syncthreads();
+    G::sync();
     double medA = qnan(), iqrA = qnan(), madA = qnan();
     if (j == 3 && N > 0 && !nanA) lanes_order_stats<CAP>(buf, g8 * STRIDE, N, medA, iqrA, madA);
-    __syncthreads();
+    G::sync();
     if (mband <= 1) iqr = 0.0;                               // statistical.py:86: 0 unless the group has two rows
     if (N <= 1) iqrA = 0.0;
+    if (nanf) { mn = qnan(); mx = qnan(); }
+    if (nanA) { mnA = qnan(); mxA = qnan(); }
 
     // ---- the 123 columns of every light curve -> LDS rows -> global
     double* o = buf + g * 128;
@@ -498,18 +490,35 @@ __device__ __forceinline__ void stat_lanes_batch(const int64_t* offsets, const d
             stat_write17(o + 102, N, meanA, sdA, mnA, mxA, medA, skewA, kurtA, madA, iqrA, b1A, b2A, a_slopeA, a_snanA, snrA,
                          nsnrA, tmnA, tmxA);
     }
-    __syncthreads();
+    G::sync();
     if (fit && j == 0) stat_cross_band(o);
-    __syncthreads();
+    G::sync();
     if (fit && orderedA) {
         double* row = out + (int64_t)obj * ld + col0;
 #pragma unroll 4
         for (int c = j; c < STAT_NCOL; c += 8) row[c] = o[c];
-    } else if (g < nk && j == 0) {
+    } else if (has_obj && j == 0) {
         const int slot = atomicAdd(fallback_count, 1);
         fallback_list[slot] = obj;
     }
-    __syncthreads();
+    G::sync();
+}
+
+// One workgroup = one batch of eight consecutive list entries.
+template <int CAP, int ITERS>
+__device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
+                                               const uint8_t* gb, const int* list, int count, StatLanesLds<CAP>& L,
+                                               double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
+    const int g = (threadIdx.x & 63) >> 3;
+    const int64_t base = (int64_t)blockIdx.x * 8;
+    int obj = -1;
+    int64_t s1 = 0, e1 = 0;
+    if (base + g < count) {
+        obj = list[base + g];
+        s1 = offsets[obj];
+        e1 = offsets[obj + 1];
+    }
+    stat_lanes_batch<CAP, ITERS>(gt, gf, ge, gb, obj, s1, e1, L.buf, out, ld, col0, fallback_list, fallback_count);
 }
 
 }  // namespace lcfe
