@@ -158,15 +158,6 @@ __device__ __forceinline__ void lanes_order_stats(const double* buf, int base, i
     mad = (r == m / 2) ? v_lo : (v_lo + v_hi) / 2.0;
 }
 
-// |df / dt| for a time step dt > 0 of normal size (the callers discard the other steps): hardware reciprocal, two
-// Newton steps, one product -- within an ulp of the division (max_slope is compared at 1e-9) at a third of its cost
-__device__ __forceinline__ double lanes_slope(double df, double dt) {
-    double inv = __builtin_amdgcn_rcp(dt);
-    inv = fma(fma(-dt, inv, 1.0), inv, inv);
-    inv = fma(fma(-dt, inv, 1.0), inv, inv);
-    return fabs(df * inv);
-}
-
 // x of the partner lane of a split band (lanes 2|3 and 6|7 of a group)
 __device__ __forceinline__ double lanes_pair(double x) { return lane_xor_fetch<1>(x); }
 __device__ __forceinline__ int lanes_pair(int x) { return lane_xor_fetch<1>(x); }
@@ -270,7 +261,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
             const double t1 = (j == 7) ? tn_w : tn_l, f1 = (j == 7) ? fn_w : fn_l;
             ordered = ordered && !(has && !(rt[it] <= t1));
             const double dt = t1 - rt[it];
-            const double sl = lanes_slope(f1 - rf[it], dt);
+            const double sl = stat_slope(f1 - rf[it], dt);
             const bool valid = has && dt > 0;
             a_snan = a_snan || (valid && is_nan(sl));
             a_slope = (valid && sl > a_slope) ? sl : a_slope;
@@ -317,7 +308,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         for (int i = 0; i + 1 < CAP; ++i) {
             const double tn = buf[col + i + 1];
             const double dt = tn - tc;
-            const double sl = lanes_slope(v[i + 1] - v[i], dt);
+            const double sl = stat_slope(v[i + 1] - v[i], dt);
             const bool valid = i + 1 < m && dt > 0;
             snan = snan || (valid && is_nan(sl));
             slope = (valid && sl > slope) ? sl : slope;
@@ -326,7 +317,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         tmx = buf[col + ((m > 0) ? m - 1 : 0)];
         if (bridge) {
             const double dt = buf[col + STRIDE] - tmx;
-            const double sl = lanes_slope(f_next - f_last, dt);
+            const double sl = stat_slope(f_next - f_last, dt);
             const bool valid = dt > 0;
             snan = snan || (valid && is_nan(sl));
             slope = (valid && sl > slope) ? sl : slope;
