@@ -71,11 +71,13 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 5;
+constexpr int kNumLists = 2 * kNumBins + 7;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
-constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light curves the lanes kernel of the tier could not take
+constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light curves of the tier the lanes kernels do not take
+constexpr int kStatL16List = 2 * kNumBins + 5;        // light curves of up to 128 rows whose bands fit 16-row lanes (r, i: 32 rows)
+constexpr int kStatL32List = 2 * kNumBins + 6;        // ... 32-row lanes (r, i: 64 rows)
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -270,12 +272,96 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
 // Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp): CAP = rows of u, g, z, y a
 // lane holds (r and i: 2 CAP over two lanes).  One ticket = eight consecutive list entries.  Light curves that do not
 // fit the shape are appended to the tier's retry list, which the one-light-curve-per-wavefront kernel of the tier takes.
-template <int CAP>
-__global__ __launch_bounds__(64, (CAP <= 32) ? 2 : 1) void stat_lanes_kernel(BatchView B, Bins bins, int bin, double* out, int ld,
-                                                                            int col0) {
+template <int CAP, int ITERS>
+__global__ __launch_bounds__(64, (CAP <= 16) ? 3 : ((CAP <= 32) ? 2 : 1)) void stat_lanes_kernel(BatchView B, Bins bins, int list, int retry,
+                                                                                         double* out, int ld, int col0) {
     __shared__ StatLanesLds<CAP> L;
-    stat_lanes_run<CAP, CAP / 2>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)bin * bins.stride, bins.counts[bin], L, out, ld,
-                                 col0, bins.lists + (int64_t)(kStatRetryList + bin) * bins.stride, &bins.counts[kStatRetryList + bin]);
+    if ((int64_t)blockIdx.x * 8 >= bins.counts[list]) return;
+    stat_lanes_run<CAP, ITERS>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)list * bins.stride, bins.counts[list], (int)blockIdx.x,
+                               L.buf, out, ld, col0, bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
+}
+
+// The 128-row tier in one launch: the batches of the 16-row-lane list, then those of the 32-row-lane list (the lists'
+// lengths are known on the device only; the grid covers n_obj / 8 + 2 batches and the rest leave at once).
+__global__ __launch_bounds__(64, 2) void stat_lanes_tier0_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
+    __shared__ StatLanesLds<32> L;
+    const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List];
+    const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3;
+    const int b = (int)blockIdx.x;
+    if (b < nb16)
+        stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b, L.buf, out, ld, col0,
+                               bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
+    else if (b < nb16 + nb32)
+        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb16, L.buf, out, ld,
+                               col0, bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
+}
+
+// Which lanes kernel takes a light curve of the 128-row tier (list `src`): 8 lanes per light curve count its rows per
+// band (1 byte per row is read); lists are appended per 128-light-curve workgroup with one atomic per list.  A light
+// curve whose bands do not fit the lanes is appended to list `unfit` (a one-light-curve-per-wavefront kernel takes it).
+constexpr int kPlanThreads = 1024;
+__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int unfit) {
+    __shared__ int wcount[kPlanThreads / 64][3];
+    __shared__ int base[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7, g8 = g << 3;
+    const int count = bins.counts[src];
+    const int64_t pos = (int64_t)blockIdx.x * (kPlanThreads / 8) + wave * 8 + g;
+    if ((int64_t)blockIdx.x * (kPlanThreads / 8) >= count) return;
+    int obj = -1, n = 0;
+    int64_t s0 = 0;
+    if (pos < count) {
+        obj = bins.lists[(int64_t)src * bins.stride + pos];
+        s0 = B.offsets[obj];
+        n = (int)(B.offsets[obj + 1] - s0);
+    }
+    // the source list holds light curves of up to 128 rows: 16 rows per lane, all loads in flight at once
+    int bb[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 8 + j;
+        bb[it] = (row < n) ? (int)B.b[s0 + row] : 256;
+    }
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    bool known = true;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int b = bb[it];
+        known = known && (b < 6 || b == 256);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cnt[k] += __builtin_popcount((unsigned int)(__ballot(b == k) >> g8) & 0xFFu);
+    }
+    known = GroupDev<8>::all(known);
+    int eff = cnt[0];
+    eff = (cnt[1] > eff) ? cnt[1] : eff;
+    eff = (cnt[4] > eff) ? cnt[4] : eff;
+    eff = (cnt[5] > eff) ? cnt[5] : eff;
+    eff = ((cnt[2] + 1) / 2 > eff) ? (cnt[2] + 1) / 2 : eff;
+    eff = ((cnt[3] + 1) / 2 > eff) ? (cnt[3] + 1) / 2 : eff;
+    const bool fits = known && n >= 1 && n <= 128;
+    const int cls = (obj < 0 || j != 0) ? -1 : ((fits && eff <= 16) ? 0 : ((fits && eff <= 32) ? 1 : 2));
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) rank = WaveDev::prefix(m);
+        if (lane == 0) wcount[wave][c] = popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int total = 0;
+        for (int w = 0; w < kPlanThreads / 64; ++w) {
+            const int c = wcount[w][threadIdx.x];
+            wcount[w][threadIdx.x] = total;
+            total += c;
+        }
+        const int dst = (threadIdx.x == 0) ? kStatL16List : ((threadIdx.x == 1) ? kStatL32List : unfit);
+        base[threadIdx.x] = total ? atomicAdd(&bins.counts[dst], total) : 0;
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        const int dst = (cls == 0) ? kStatL16List : ((cls == 1) ? kStatL32List : unfit);
+        bins.lists[(int64_t)dst * bins.stride + base[cls] + wcount[wave][cls] + rank] = obj;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1203,14 +1289,28 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
     return 0;
 }
 
-template <int CAP>
-int launch_stat_lanes(const BatchView& B, const Bins& bins, int bin, double* out, int ld, int col0, hipStream_t stream,
-                      int dev, unsigned long long* ticket) {
+template <int CAP, int ITERS>
+int launch_stat_lanes(const BatchView& B, const Bins& bins, int list, int retry, double* out, int ld, int col0, hipStream_t stream) {
     // one workgroup per batch of eight list entries; the list length is known on the device only, so the grid covers
     // the whole batch and the workgroups behind the list's end leave at once
     const int64_t grid = (B.n_obj + 7) / 8;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((stat_lanes_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0);
+    hipLaunchKernelGGL((stat_lanes_kernel<CAP, ITERS>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, list, retry, out, ld, col0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int unfit, hipStream_t stream) {
+    const int64_t grid = (B.n_obj + kPlanThreads / 8 - 1) / (kPlanThreads / 8);
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL(stat_plan_kernel, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, unfit);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_stat_lanes_tier0(const BatchView& B, const Bins& bins, int retry, double* out, int ld, int col0, hipStream_t stream) {
+    const int64_t grid = (B.n_obj + 7) / 8 + 2;
+    hipLaunchKernelGGL(stat_lanes_tier0_kernel, dim3((unsigned)grid), dim3(64), 0, stream, B, bins, retry, out, ld, col0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1232,11 +1332,18 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     unsigned long long* tk = tickets + SET_STAT * 8;
     // the tier kernels are independent (disjoint objects): with side streams they are enqueued side by side, so the
     // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch
-    const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
     const bool lanes = stat_lanes_enabled();
+    const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
     const bool lanes64 = getenv("LCFE_STAT_LANES64") != nullptr;
     hipEvent_t ev_fork = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
     struct Cleanup { hipEvent_t* e[3]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_j1, &ev_j2}};
+    if (lanes) {
+        // light curves of the 128-row tier the lanes kernels cannot take join the 256-row tier's list when that tier
+        // runs, else a list of their own
+        const int rc = launch_stat_plan(B, bins, 0, (last >= 1) ? 1 : kStatRetryList, stream);
+        if (rc) return rc;
+        ++*n_launch;
+    }
     if (fork) {
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_fork, stream));
@@ -1250,15 +1357,17 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         switch (ti) {
             case 0:
                 if (lanes) {
-                    rc = launch_stat_lanes<32>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
-                    if (!rc) rc = launch_stat_lean<128>(B, bins, kStatRetryList + 0, out, ld, col0, q, dev, tk + 6, 512);
+                    // (the plan kernel ran before the fork: it appends to the 256-row tier's list); a light curve whose rows
+                    // turn out not to ascend in time goes to the general kernel's list
+                    rc = launch_stat_lanes_tier0(B, bins, kStatFallbackList, out, ld, col0, q);
+                    if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, q, dev, tk + 6, 512);
                 } else {
                     rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
                 }
                 break;
             case 1:
                 if (lanes && lanes64) {
-                    rc = launch_stat_lanes<64>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
+                    rc = launch_stat_lanes<64, 32>(B, bins, ti, kStatRetryList + 1, out, ld, col0, q);
                     if (!rc) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q, dev, tk + 7, 512);
                 } else {
                     rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti);

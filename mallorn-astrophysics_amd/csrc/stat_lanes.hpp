@@ -504,13 +504,13 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     G::sync();
 }
 
-// One workgroup = one batch of eight consecutive list entries.
+// One workgroup = one batch (`batch`) of eight consecutive list entries; `buf`: 64 x (CAP + 1) doubles of LDS.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
-                                               const uint8_t* gb, const int* list, int count, StatLanesLds<CAP>& L,
+                                               const uint8_t* gb, const int* list, int count, int batch, double* buf,
                                                double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
     const int g = (threadIdx.x & 63) >> 3;
-    const int64_t base = (int64_t)blockIdx.x * 8;
+    const int64_t base = (int64_t)batch * 8;
     int obj = -1;
     int64_t s1 = 0, e1 = 0;
     if (base + g < count) {
@@ -518,7 +518,7 @@ __device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const dou
         s1 = offsets[obj];
         e1 = offsets[obj + 1];
     }
-    stat_lanes_batch<CAP, ITERS>(gt, gf, ge, gb, obj, s1, e1, L.buf, out, ld, col0, fallback_list, fallback_count);
+    stat_lanes_batch<CAP, ITERS>(gt, gf, ge, gb, obj, s1, e1, buf, out, ld, col0, fallback_list, fallback_count);
 }
 
 }  // namespace lcfe
