@@ -71,13 +71,14 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 7;
+constexpr int kNumLists = 2 * kNumBins + 8;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
 constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light curves of the tier the lanes kernels do not take
 constexpr int kStatL16List = 2 * kNumBins + 5;        // light curves of up to 128 rows whose bands fit 16-row lanes (r, i: 32 rows)
 constexpr int kStatL32List = 2 * kNumBins + 6;        // ... 32-row lanes (r, i: 64 rows)
+constexpr int kStatL32xList = 2 * kNumBins + 7;       // light curves of up to 256 rows whose bands fit 32-row lanes
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -227,8 +228,10 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
     using W = WaveDev;
     const int count = bins.counts[bin];
     const int* list = bins.lists + (int64_t)bin * bins.stride;
-    const int per_wave = count / (4 * (int)gridDim.x);
-    chunk = (per_wave < 1) ? 1 : ((per_wave < chunk) ? per_wave : chunk);
+    // tickets of at least two light curves: one counter serves about 90 tickets per microsecond, which a statistics
+    // tier of 20 000 light curves would otherwise spend more time on than on the light curves
+    const int per_wave = count / (2 * (int)gridDim.x);
+    chunk = (per_wave < 2) ? 2 : ((per_wave < chunk) ? per_wave : chunk);
     LCFE_PT_INIT();
     LCFE_PT0();
     for (;;) {
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(64, 2) void stat_lanes_tier0_kernel(BatchView B, Bi
 // band (1 byte per row is read); lists are appended per 128-light-curve workgroup with one atomic per list.  A light
 // curve whose bands do not fit the lanes is appended to list `unfit` (a one-light-curve-per-wavefront kernel takes it).
 constexpr int kPlanThreads = 1024;
-__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int unfit) {
+template <int ITERS>
+__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int dst16, int dst32, int unfit) {
     __shared__ int wcount[kPlanThreads / 64][3];
     __shared__ int base[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7, g8 = g << 3;
@@ -314,22 +318,27 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
         s0 = B.offsets[obj];
         n = (int)(B.offsets[obj + 1] - s0);
     }
-    // the source list holds light curves of up to 128 rows: 16 rows per lane, all loads in flight at once
-    int bb[16];
+    // the source list holds light curves of up to 8 ITERS rows: ITERS rows per lane, all loads in flight at once
+    int bb[ITERS];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         const int row = it * 8 + j;
         bb[it] = (row < n) ? (int)B.b[s0 + row] : 256;
     }
-    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    // rows per band: six 10-bit counters in one 64-bit word per lane (codes above 5 count in the bits that fall off),
+    // summed over the 8 lanes of the light curve
+    unsigned long long acc = 0;
     bool known = true;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         const int b = bb[it];
         known = known && (b < 6 || b == 256);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cnt[k] += __builtin_popcount((unsigned int)(__ballot(b == k) >> g8) & 0xFFu);
+        acc += 1ull << (10 * ((b < 6) ? b : 6));
     }
+    acc = GroupDev<8>::reduce((long long)acc, [](long long x, long long y) { return x + y; });
+    int cnt[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cnt[k] = (int)(acc >> (10 * k)) & 1023;
     known = GroupDev<8>::all(known);
     int eff = cnt[0];
     eff = (cnt[1] > eff) ? cnt[1] : eff;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
     eff = (cnt[5] > eff) ? cnt[5] : eff;
     eff = ((cnt[2] + 1) / 2 > eff) ? (cnt[2] + 1) / 2 : eff;
     eff = ((cnt[3] + 1) / 2 > eff) ? (cnt[3] + 1) / 2 : eff;
-    const bool fits = known && n >= 1 && n <= 128;
+    const bool fits = known && n >= 1 && n <= 8 * ITERS;
     const int cls = (obj < 0 || j != 0) ? -1 : ((fits && eff <= 16) ? 0 : ((fits && eff <= 32) ? 1 : 2));
     int rank = 0;
 #pragma unroll
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
         if (lane == 0) wcount[wave][c] = popcll(m);
     }
     __syncthreads();
+    // (dst16 == dst32 is allowed: the two classes then take consecutive slices of one list)
     if (threadIdx.x < 3) {
         int total = 0;
         for (int w = 0; w < kPlanThreads / 64; ++w) {
@@ -354,12 +364,12 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
             wcount[w][threadIdx.x] = total;
             total += c;
         }
-        const int dst = (threadIdx.x == 0) ? kStatL16List : ((threadIdx.x == 1) ? kStatL32List : unfit);
+        const int dst = (threadIdx.x == 0) ? dst16 : ((threadIdx.x == 1) ? dst32 : unfit);
         base[threadIdx.x] = total ? atomicAdd(&bins.counts[dst], total) : 0;
     }
     __syncthreads();
     if (cls >= 0) {
-        const int dst = (cls == 0) ? kStatL16List : ((cls == 1) ? kStatL32List : unfit);
+        const int dst = (cls == 0) ? dst16 : ((cls == 1) ? dst32 : unfit);
         bins.lists[(int64_t)dst * bins.stride + base[cls] + wcount[wave][cls] + rank] = obj;
     }
 }
@@ -1300,10 +1310,11 @@ int launch_stat_lanes(const BatchView& B, const Bins& bins, int list, int retry,
     return 0;
 }
 
-int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int unfit, hipStream_t stream) {
+template <int ITERS>
+int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int dst16, int dst32, int unfit, hipStream_t stream) {
     const int64_t grid = (B.n_obj + kPlanThreads / 8 - 1) / (kPlanThreads / 8);
     if (grid < 1) return 0;
-    hipLaunchKernelGGL(stat_plan_kernel, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, unfit);
+    hipLaunchKernelGGL(stat_plan_kernel<ITERS>, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, dst16, dst32, unfit);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1315,9 +1326,7 @@ int launch_stat_lanes_tier0(const BatchView& B, const Bins& bins, int retry, dou
     return 0;
 }
 
-// LCFE_STAT_LANES=0 keeps the one-light-curve-per-wavefront kernel for the 128-row tier (A/B measurements);
-// LCFE_STAT_LANES64=1 also runs the 256-row tier eight light curves per wavefront (one wavefront per SIMD at that
-// register count: slower than stat_lean_kernel<256> as measured)
+// LCFE_STAT_LANES=0 keeps the one-light-curve-per-wavefront kernels for the 128- and 256-row tiers (A/B measurements)
 static bool stat_lanes_enabled() {
     const char* e = getenv("LCFE_STAT_LANES");
     return !(e && e[0] == '0');
@@ -1330,55 +1339,61 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     int last = 0;
     while (last < 4 && kTiers[last] < max_len) ++last;
     unsigned long long* tk = tickets + SET_STAT * 8;
-    // the tier kernels are independent (disjoint objects): with side streams they are enqueued side by side, so the
-    // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch
+    // The tier kernels are independent (disjoint objects): with side streams they are enqueued side by side, so the
+    // ramp-down of one tier is filled by the waves of the others; they are joined before the fallback launch.
+    //   s2:     the tiers of more than 256 rows, from the start
+    //   stream: the plan kernels (which lanes kernel takes a light curve of up to 256 rows), then the lanes kernels
+    //   s1:     after the plan kernels, the 256-row tier's one-light-curve-per-wavefront kernel
     const bool lanes = stat_lanes_enabled();
     const bool fork = (s1 != stream) && (s2 != stream) && last >= 1;
-    const bool lanes64 = getenv("LCFE_STAT_LANES64") != nullptr;
-    hipEvent_t ev_fork = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
-    struct Cleanup { hipEvent_t* e[3]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_j1, &ev_j2}};
-    if (lanes) {
-        // light curves of the 128-row tier the lanes kernels cannot take join the 256-row tier's list when that tier
-        // runs, else a list of their own
-        const int rc = launch_stat_plan(B, bins, 0, (last >= 1) ? 1 : kStatRetryList, stream);
-        if (rc) return rc;
-        ++*n_launch;
-    }
+    hipEvent_t ev_fork = nullptr, ev_plan = nullptr, ev_j1 = nullptr, ev_j2 = nullptr;
+    struct Cleanup { hipEvent_t* e[4]; ~Cleanup() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } cleanup{{&ev_fork, &ev_plan, &ev_j1, &ev_j2}};
+    hipStream_t q_long = fork ? s2 : stream, q_mid = fork ? s1 : stream;
     if (fork) {
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_fork, stream));
-        HIP_TRY(hipStreamWaitEvent(s1, ev_fork, 0));
         HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
     }
-    for (int ti = 0; ti <= last; ++ti) {
+    for (int ti = 2; ti <= last; ++ti) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
-        hipStream_t q = !fork ? stream : ((ti % 3 == 0) ? stream : ((ti % 3 == 1) ? s1 : s2));
         int rc = 0;
         switch (ti) {
-            case 0:
-                if (lanes) {
-                    // (the plan kernel ran before the fork: it appends to the 256-row tier's list); a light curve whose rows
-                    // turn out not to ascend in time goes to the general kernel's list
-                    rc = launch_stat_lanes_tier0(B, bins, kStatFallbackList, out, ld, col0, q);
-                    if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, q, dev, tk + 6, 512);
-                } else {
-                    rc = launch_stat_lean<128>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
-                }
-                break;
-            case 1:
-                if (lanes && lanes64) {
-                    rc = launch_stat_lanes<64, 32>(B, bins, ti, kStatRetryList + 1, out, ld, col0, q);
-                    if (!rc) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q, dev, tk + 7, 512);
-                } else {
-                    rc = launch_stat_lean<256>(B, bins, ti, out, ld, col0, q, dev, tk + ti);
-                }
-                break;
-            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q, dev, tk + ti); break;
-            case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
-            case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q, dev, tk + ti); break;
+            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q_long, dev, tk + ti); break;
+            case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q_long, dev, tk + ti); break;
+            case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q_long, dev, tk + ti); break;
         }
         if (rc) return rc;
         ++*n_launch;
+    }
+    if (lanes) {
+        // light curves of the 128-row tier the lanes kernels cannot take join the 256-row tier's list when that tier
+        // runs, else a list of their own
+        int rc = launch_stat_plan<16>(B, bins, 0, kStatL16List, kStatL32List, (last >= 1) ? 1 : kStatRetryList, stream);
+        // the 256-row tier (and what the 128-row tier handed over): 32-row lanes, or the one-light-curve-per-wavefront kernel
+        if (!rc && last >= 1) rc = launch_stat_plan<32>(B, bins, 1, kStatL32xList, kStatL32xList, kStatRetryList + 1, stream);
+        if (rc) return rc;
+        *n_launch += 2;
+    }
+    if (fork) {
+        HIP_TRY(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_plan, stream));
+        HIP_TRY(hipStreamWaitEvent(s1, ev_plan, 0));
+    }
+    {
+        int rc = 0;
+        if (lanes) {
+            // a light curve whose rows turn out not to ascend in time goes to the general kernel's list
+            if (last >= 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q_mid, dev, tk + 1);
+            if (!rc) rc = launch_stat_lanes_tier0(B, bins, kStatFallbackList, out, ld, col0, stream);
+            if (!rc && last >= 1) rc = launch_stat_lanes<32, 32>(B, bins, kStatL32xList, kStatFallbackList, out, ld, col0, stream);
+            if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, stream, dev, tk + 6, 512);
+            *n_launch += 3;
+        } else {
+            if (last >= 1) rc = launch_stat_lean<256>(B, bins, 1, out, ld, col0, q_mid, dev, tk + 1);
+            if (!rc) rc = launch_stat_lean<128>(B, bins, 0, out, ld, col0, stream, dev, tk + 0);
+            *n_launch += 2;
+        }
+        if (rc) return rc;
     }
     if (fork) {
         HIP_TRY(hipEventCreateWithFlags(&ev_j1, hipEventDisableTiming));

@@ -163,6 +163,11 @@ struct GroupDev {
     }
     template <int CTRL>
     static __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+    template <int CTRL>
+    static __device__ __forceinline__ long long dpp(long long b) {
+        const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+        return ((long long)hi << 32) | (unsigned int)lo;
+    }
     // quad_perm(1,0,3,2) = 0xB1, quad_perm(2,3,0,1) = 0x4E, row_half_mirror = 0x141
     template <class V, class Op>
     static __device__ __forceinline__ V reduce(V v, Op op) {
