@@ -284,19 +284,26 @@ __global__ __launch_bounds__(64, (CAP <= 16) ? 3 : ((CAP <= 32) ? 2 : 1)) void s
                                L.buf, out, ld, col0, bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
 }
 
-// The 128-row tier in one launch: the batches of the 16-row-lane list, then those of the 32-row-lane list (the lists'
-// lengths are known on the device only; the grid covers n_obj / 8 + 2 batches and the rest leave at once).
-__global__ __launch_bounds__(64, 2) void stat_lanes_tier0_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
+// The lanes kernels in one launch: the batches of the 16-row-lane list, then those of the 32-row-lane lists of the
+// 128- and the 256-row tier (the lists' lengths are known on the device only; the grid covers n_obj / 8 + 3 batches
+// and the rest leave at once).
+__global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
     __shared__ StatLanesLds<32> L;
-    const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List];
-    const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3;
+    const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List], c32x = bins.counts[kStatL32xList];
+    const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3, nb32x = (c32x + 7) >> 3;
     const int b = (int)blockIdx.x;
-    if (b < nb16)
-        stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b, L.buf, out, ld, col0,
-                               bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
-    else if (b < nb16 + nb32)
-        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb16, L.buf, out, ld,
-                               col0, bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
+    int* rl = bins.lists + (int64_t)retry * bins.stride;
+    int* rc = &bins.counts[retry];
+    // (the long batches first: they are the ones whose tail would otherwise stick out)
+    if (b < nb32x)
+        stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, L.buf, out, ld,
+                               col0, rl, rc);
+    else if (b < nb32x + nb32)
+        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb32x, L.buf, out,
+                               ld, col0, rl, rc);
+    else if (b < nb32x + nb32 + nb16)
+        stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b - nb32x - nb32, L.buf,
+                               out, ld, col0, rl, rc);
 }
 
 // Which lanes kernel takes a light curve of the 128-row tier (list `src`): 8 lanes per light curve count its rows per
@@ -307,7 +314,7 @@ template <int ITERS>
 __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int dst16, int dst32, int unfit) {
     __shared__ int wcount[kPlanThreads / 64][3];
     __shared__ int base[3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7, g8 = g << 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7;
     const int count = bins.counts[src];
     const int64_t pos = (int64_t)blockIdx.x * (kPlanThreads / 8) + wave * 8 + g;
     if ((int64_t)blockIdx.x * (kPlanThreads / 8) >= count) return;
@@ -1319,9 +1326,9 @@ int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int dst16, i
     return 0;
 }
 
-int launch_stat_lanes_tier0(const BatchView& B, const Bins& bins, int retry, double* out, int ld, int col0, hipStream_t stream) {
-    const int64_t grid = (B.n_obj + 7) / 8 + 2;
-    hipLaunchKernelGGL(stat_lanes_tier0_kernel, dim3((unsigned)grid), dim3(64), 0, stream, B, bins, retry, out, ld, col0);
+int launch_stat_lanes_all(const BatchView& B, const Bins& bins, int retry, double* out, int ld, int col0, hipStream_t stream) {
+    const int64_t grid = (B.n_obj + 7) / 8 + 3;
+    hipLaunchKernelGGL(stat_lanes_all_kernel, dim3((unsigned)grid), dim3(64), 0, stream, B, bins, retry, out, ld, col0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1384,10 +1391,9 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         if (lanes) {
             // a light curve whose rows turn out not to ascend in time goes to the general kernel's list
             if (last >= 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q_mid, dev, tk + 1);
-            if (!rc) rc = launch_stat_lanes_tier0(B, bins, kStatFallbackList, out, ld, col0, stream);
-            if (!rc && last >= 1) rc = launch_stat_lanes<32, 32>(B, bins, kStatL32xList, kStatFallbackList, out, ld, col0, stream);
+            if (!rc) rc = launch_stat_lanes_all(B, bins, kStatFallbackList, out, ld, col0, stream);
             if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, stream, dev, tk + 6, 512);
-            *n_launch += 3;
+            *n_launch += 2;
         } else {
             if (last >= 1) rc = launch_stat_lean<256>(B, bins, 1, out, ld, col0, q_mid, dev, tk + 1);
             if (!rc) rc = launch_stat_lean<128>(B, bins, 0, out, ld, col0, stream, dev, tk + 0);
