@@ -286,7 +286,7 @@ def main():
         "kernel_ms_note": ("per-set HIP-event times on one stream (LCFE_SERIAL=1)" if os.environ.get("LCFE_SERIAL") == "1" else
                            "statistics (+ binning) runs alone; the other sets run concurrently on forked streams, "
                            "so their event times overlap and do not add up to ms_per_step"),
-        "roofline": {"kernel": "stat_lean_kernel<128|256|512> (+ bin_kernel, fallback launch)" if rk == "stat" else f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"kernel": "statistics set: bin_kernel, stat_plan_kernel<16|32>, stat_lanes_all_kernel, stat_lean_kernel<256|512>, fallback launch" if rk == "stat" else f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": per_set[rk]},
     }

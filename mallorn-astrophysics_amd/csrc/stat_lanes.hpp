@@ -493,11 +493,19 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     G::sync();
     if (fit && j == 0) stat_cross_band(o);
     G::sync();
-    if (fit && orderedA) {
-        double* row = out + (int64_t)obj * ld + col0;
-#pragma unroll 4
-        for (int c = j; c < STAT_NCOL; c += 8) row[c] = o[c];
-    } else if (has_obj && j == 0) {
+    // rows to global memory, one light curve at a time on the whole wavefront (two 512-byte stores per row)
+    const bool done = fit && orderedA;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int obj_r = __builtin_amdgcn_readlane(done ? obj : -1, 8 * r);
+        if (obj_r >= 0) {
+            double* row = out + (int64_t)obj_r * ld + col0;
+            const double* src = buf + r * 128;
+            row[lane] = src[lane];
+            if (lane + 64 < STAT_NCOL) row[lane + 64] = src[lane + 64];
+        }
+    }
+    if (!done && has_obj && j == 0) {
         const int slot = atomicAdd(fallback_count, 1);
         fallback_list[slot] = obj;
     }
