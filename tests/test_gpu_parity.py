@@ -106,6 +106,65 @@ def test_statistics_band_shapes():
     assert not bad, "\n".join(bad)
 
 
+def test_statistics_lane_routes():
+    """The eight-light-curves-per-wavefront statistics kernels (stat_lanes.hpp): band lengths on both sides of every
+    routing threshold of the plan kernel (16- / 32-row lanes, r and i split over two lanes, 128 / 256 rows), bands of
+    0 / 1 / 2 rows, odd and even r / i halves, negative and zero times, NaN and inf fluxes in either half, rows out of
+    time order and unknown band codes inside lane-eligible light curves, and batch lengths that do not fill the last
+    group of eight -- each object against the oracle, and the batch in a different order."""
+    rng = np.random.default_rng(77)
+    objs = []
+
+    def add(counts, t0=59000.0, nan_band=None, inf_band=None, shuffle=False, unknown=False, dup_t=False):
+        n = int(sum(counts))
+        t = np.sort(t0 + rng.uniform(0, 500, n))
+        if dup_t and n > 3:
+            t[2] = t[1]
+        b = rng.permutation(np.repeat(np.arange(6), counts)).astype(np.int64)
+        f = 20 * np.exp(-0.5 * ((t - t0 - 200) / 50) ** 2) * (1 + 0.3 * b) + rng.normal(0, 1.5, n)
+        e = rng.uniform(0.3, 2.0, n)
+        e[rng.random(n) < 0.05] = 0.0                     # rows the SNR mean leaves out
+        if nan_band is not None:
+            f[np.flatnonzero(b == nan_band)[-2]] = np.nan  # second half of a split band
+        if inf_band is not None:
+            f[np.flatnonzero(b == inf_band)[0]] = np.inf
+        if unknown:
+            b[rng.choice(n, 2, replace=False)] = 200
+        if shuffle:
+            p = rng.permutation(n)
+            t, f, e, b = t[p], f[p], e[p], b[p]
+        objs.append((t, f, e, b))
+
+    for c in ([16, 16, 32, 32, 16, 16], [17, 16, 32, 32, 16, 16], [16, 16, 33, 32, 16, 16], [16, 16, 32, 32, 16, 0],
+              [32, 32, 64, 64, 32, 32], [33, 32, 64, 64, 32, 31], [32, 32, 65, 64, 32, 31], [32, 32, 63, 63, 32, 32],
+              [0, 0, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1], [2, 0, 2, 3, 0, 1], [0, 0, 0, 0, 0, 5], [5, 0, 0, 0, 0, 0],
+              [3, 9, 31, 30, 20, 7], [10, 20, 41, 40, 30, 12], [4, 4, 64, 4, 4, 4], [4, 4, 4, 64, 4, 48],
+              [8, 8, 40, 40, 16, 16], [20, 20, 20, 20, 24, 24], [30, 30, 60, 60, 30, 30], [12, 12, 48, 47, 5, 5]):
+        add(c)
+    add([10, 10, 30, 30, 10, 10], t0=-250.0)              # times around zero: slots behind a lane's rows hold 0.0
+    add([10, 10, 30, 30, 10, 10], t0=0.0)
+    add([6, 6, 21, 20, 6, 6], nan_band=2)
+    add([6, 6, 20, 21, 6, 6], nan_band=3)
+    add([6, 6, 20, 21, 6, 6], inf_band=3)
+    add([6, 6, 20, 21, 6, 6], nan_band=0, inf_band=2)
+    add([6, 6, 20, 21, 6, 6], dup_t=True)
+    add([6, 6, 20, 21, 6, 6], shuffle=True)               # general kernel
+    add([6, 6, 20, 21, 6, 6], unknown=True)               # general kernel
+    add([30, 30, 60, 60, 30, 30], shuffle=True)
+    add([30, 30, 60, 60, 30, 30], unknown=True)
+    lc = synth.from_objects(objs)
+    got = extract_csr("stat", lc)
+    ref = oracle.extract("stat", lc)
+    bad = parity.compare(got, ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+    # the same light curves in another order and another batch length (3 light curves in the last group of 8 -> 5)
+    order = rng.permutation(len(objs))[:-2]
+    lc2 = synth.from_objects([objs[i] for i in order])
+    got2 = extract_csr("stat", lc2)
+    key = lambda m: np.nan_to_num(m, nan=-7.25e300)
+    assert np.array_equal(key(got2), key(got[order])), "a light curve's statistics depend on its batch"
+
+
 def test_special_values_fuzz():
     """NaN, +-inf, +-0, huge and tiny fluxes, NaN / inf / zero / negative errors, duplicated time stamps,
     constant bands and heavy ties, injected into seeded light curves: every streaming set must still agree
