@@ -272,21 +272,12 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
     LCFE_PT_FLUSH();
 }
 
-// Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp): CAP = rows of u, g, z, y a
-// lane holds (r and i: 2 CAP over two lanes).  One ticket = eight consecutive list entries.  Light curves that do not
-// fit the shape are appended to the tier's retry list, which the one-light-curve-per-wavefront kernel of the tier takes.
-template <int CAP, int ITERS>
-__global__ __launch_bounds__(64, (CAP <= 16) ? 3 : ((CAP <= 32) ? 2 : 1)) void stat_lanes_kernel(BatchView B, Bins bins, int list, int retry,
-                                                                                         double* out, int ld, int col0) {
-    __shared__ StatLanesLds<CAP> L;
-    if ((int64_t)blockIdx.x * 8 >= bins.counts[list]) return;
-    stat_lanes_run<CAP, ITERS>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)list * bins.stride, bins.counts[list], (int)blockIdx.x,
-                               L.buf, out, ld, col0, bins.lists + (int64_t)retry * bins.stride, &bins.counts[retry]);
-}
-
-// The lanes kernels in one launch: the batches of the 16-row-lane list, then those of the 32-row-lane lists of the
-// 128- and the 256-row tier (the lists' lengths are known on the device only; the grid covers n_obj / 8 + 3 batches
-// and the rest leave at once).
+// Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp: CAP = rows of u, g, z, y a lane
+// holds -- r and i: 2 CAP over two lanes; ITERS = rows / 8 of the light curve).  One workgroup = one batch of eight
+// consecutive entries of one of the three lists the plan kernels fill: 32-row lanes for light curves of up to 256
+// rows, 32- and 16-row lanes for those of up to 128 rows.  The lists' lengths are known on the device only; the grid
+// covers n_obj / 8 + 3 batches and the workgroups behind the last batch leave at once.  A light curve whose rows turn
+// out not to ascend in time is appended to list `retry`.
 __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
     __shared__ StatLanesLds<32> L;
     const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List], c32x = bins.counts[kStatL32xList];
@@ -296,14 +287,14 @@ __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins
     int* rc = &bins.counts[retry];
     // (the long batches first: they are the ones whose tail would otherwise stick out)
     if (b < nb32x)
-        stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, L.buf, out, ld,
+        stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, L.buf, L.all_rows, out, ld,
                                col0, rl, rc);
     else if (b < nb32x + nb32)
-        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb32x, L.buf, out,
+        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb32x, L.buf, L.all_rows, out,
                                ld, col0, rl, rc);
     else if (b < nb32x + nb32 + nb16)
         stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b - nb32x - nb32, L.buf,
-                               out, ld, col0, rl, rc);
+                               L.all_rows, out, ld, col0, rl, rc);
 }
 
 // Which lanes kernel takes a light curve of the 128-row tier (list `src`): 8 lanes per light curve count its rows per
@@ -1302,17 +1293,6 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
     if (grid < 1) return 0;
     hipLaunchKernelGGL((stat_lean_kernel<CAP>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, bin, out, ld, col0,
                        ticket, 8);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int CAP, int ITERS>
-int launch_stat_lanes(const BatchView& B, const Bins& bins, int list, int retry, double* out, int ld, int col0, hipStream_t stream) {
-    // one workgroup per batch of eight list entries; the list length is known on the device only, so the grid covers
-    // the whole batch and the workgroups behind the list's end leave at once
-    const int64_t grid = (B.n_obj + 7) / 8;
-    if (grid < 1) return 0;
-    hipLaunchKernelGGL((stat_lanes_kernel<CAP, ITERS>), dim3((unsigned)grid), dim3(64), 0, stream, B, bins, list, retry, out, ld, col0);
     HIP_TRY(hipGetLastError());
     return 0;
 }

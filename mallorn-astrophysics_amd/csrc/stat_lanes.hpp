@@ -117,6 +117,7 @@ template <int CAP>
 struct StatLanesLds {
     static constexpr int STRIDE = CAP + 1;       // odd number of doubles: a column per lane without bank conflicts
     double buf[64 * STRIDE];
+    double all_rows[8 * 17];                     // the all-rows columns of the eight light curves, stored as they get ready
 };
 
 // element `idx` of an ascending sequence dumped lane-major from column `base` on (CAP registers per lane)
@@ -168,7 +169,7 @@ __device__ __forceinline__ int lanes_pair(int x) { return lane_xor_fetch<1>(x); 
 // loads.  Not inlined: the caller's loop state stays out of this function's register budget.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double* gf, const double* ge, const uint8_t* gb, int obj,
-                                              int64_t s1, int64_t e1, double* buf, double* out, int ld, int col0,
+                                              int64_t s1, int64_t e1, double* buf, double* all_rows, double* out, int ld, int col0,
                                               int* fallback_list, int* fallback_count) {
     using G = GroupDev<8>;
     constexpr int STRIDE = StatLanesLds<CAP>::STRIDE;
@@ -366,6 +367,15 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         snan = snan | (p_snan != 0);
     }
     const double mean = s / mband, meanA = sA / N;
+    double* oa = all_rows + (g8 >> 3) * 17;              // the all-rows columns leave the registers as soon as they are known
+    if (j == 3) {
+        oa[0] = (double)N;
+        oa[1] = meanA;
+        oa[13] = (N > 1) ? (a_snanA ? qnan() : (a_slopeA < 0 ? 0.0 : a_slopeA)) : 0.0;
+        oa[14] = (nsnrA > 0) ? snrA / nsnrA : qnan();
+        oa[15] = (N > 1) ? (tmxA - tmnA) : 0.0;
+        oa[16] = (N > 1) ? (tmxA - tmnA) / (double)(N - 1) : 0.0;
+    }
 
     // ---- behind the lane's rows the band mean: the centred band passes need no per-element mask (a padded slot adds
     //      exactly 0 and counts as "inside"); the all-rows terms are masked
@@ -439,6 +449,13 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     double skew, kurt, b1, b2, skewA, kurtA, b1A, b2A;
     finish(mband, sd, s3, s4, c1, c2, skew, kurt, b1, b2);
     finish(N, sdA, s3A, s4A, c1A, c2A, skewA, kurtA, b1A, b2A);
+    if (j == 3) {
+        oa[2] = sdA;
+        oa[6] = skewA;
+        oa[7] = kurtA;
+        oa[11] = b1A;
+        oa[12] = b2A;
+    }
 
 
     // ---- order statistics and extrema: register sort per lane, then merges across the lanes
@@ -477,6 +494,14 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     if (N <= 1) iqrA = 0.0;
     if (nanf) { mn = qnan(); mx = qnan(); }
     if (nanA) { mnA = qnan(); mxA = qnan(); }
+    if (j == 3) {
+        oa[3] = mnA;
+        oa[4] = mxA;
+        oa[8] = mxA - mnA;
+        oa[5] = medA;
+        oa[9] = madA;
+        oa[10] = iqrA;
+    }
 
     // ---- the 123 columns of every light curve -> LDS rows -> global
     double* o = buf + g * 128;
@@ -486,9 +511,11 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
             if (mband == 0) stat_empty_group(ob, nullptr);
             else stat_write17(ob, mband, mean, sd, mn, mx, med, skew, kurt, mad, iqr, b1, b2, slope, snan, snr, nsnr, tmn, tmx);
         }
-        if (j == 3)
-            stat_write17(o + 102, N, meanA, sdA, mnA, mxA, medA, skewA, kurtA, madA, iqrA, b1A, b2A, a_slopeA, a_snanA, snrA,
-                         nsnrA, tmnA, tmxA);
+    }
+    G::sync();
+    if (fit) {
+#pragma unroll
+        for (int c = j; c < 17; c += 8) o[102 + c] = oa[c];
     }
     G::sync();
     if (fit && j == 0) stat_cross_band(o);
@@ -515,7 +542,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
 // One workgroup = one batch (`batch`) of eight consecutive list entries; `buf`: 64 x (CAP + 1) doubles of LDS.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
-                                               const uint8_t* gb, const int* list, int count, int batch, double* buf,
+                                               const uint8_t* gb, const int* list, int count, int batch, double* buf, double* all_rows,
                                                double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
     const int g = (threadIdx.x & 63) >> 3;
     const int64_t base = (int64_t)batch * 8;
@@ -526,7 +553,7 @@ __device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const dou
         s1 = offsets[obj];
         e1 = offsets[obj + 1];
     }
-    stat_lanes_batch<CAP, ITERS>(gt, gf, ge, gb, obj, s1, e1, buf, out, ld, col0, fallback_list, fallback_count);
+    stat_lanes_batch<CAP, ITERS>(gt, gf, ge, gb, obj, s1, e1, buf, all_rows, out, ld, col0, fallback_list, fallback_count);
 }
 
 }  // namespace lcfe
