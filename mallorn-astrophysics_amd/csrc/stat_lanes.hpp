@@ -12,20 +12,24 @@
 //     lane of the group   0   1   2        3         4   5   6        7
 //     rows                u   g   r first  r second  z   y   i first  i second
 //
-// Phases (one LDS buffer of 64 columns x (CAP + 1) doubles per wavefront, reused):
-//   A  positions: 8 rows of every light curve per trip; a row's slot = number of earlier rows of its band
-//      (ballots); nothing but the band byte is read
-//   F  fluxes -> LDS (column = lane that owns the band half) -> registers v[0..CAP]; sums, extrema
-//   T  times  -> LDS -> band slopes against the register-resident fluxes; the all-rows slope and the
-//      "rows ascend in time" check are taken on the fly from the file-order neighbours
-//   Q  |f| / e -> LDS -> SNR sums
-//   then the two centred passes (band and all-rows moments side by side, the all-rows sums being the
-//   8-lane sums of the lanes' partials), the register sort, and the all-rows order statistics from a
-//   bitonic MERGE of the eight sorted lanes (the first level of which is the merge of the r and i halves).
-//   Order statistics are read off LDS dumps of the sorted registers by one lane per sequence.
-// A light curve that does not fit (a band longer than its lane(s), unknown band code, rows not in time
-// order) goes to the general kernel's list.  Same arithmetic per element as stat.hpp (two-pass moments,
-// exact counts, numpy's percentile interpolation, exact MAD); only the association of the sums differs.
+// One workgroup (= one wavefront) takes one batch of eight light curves; lane j of a group first holds rows j, j + 8,
+// ... of its light curve (t, f, e, band code) in registers from ONE round of loads.  Phases (one LDS buffer of
+// 64 columns x (CAP + 1) doubles per wavefront, reused):
+//   A  positions: a row's slot = number of earlier rows of its band (ballots over the 8 rows of a trip); per row also
+//      the all-rows slope and the "rows ascend in time" check from the file-order neighbours (next lane / next trip)
+//      and the SNR term |f| / e
+//   F  fluxes -> LDS (column = lane that owns the band half) -> registers v[0..CAP); sums, NaN flags
+//   T  times  -> LDS -> band slopes against the register-resident fluxes
+//   Q  SNR terms -> LDS -> sums
+//   then the two centred passes (band and all-rows moments side by side, select-free on a copy padded with the band
+//   mean; the all-rows sums are the 8-lane sums of the lanes' partials), the register sort, and the all-rows order
+//   statistics from a bitonic MERGE of the eight sorted lanes (whose first level is the merge of the r and i halves).
+//   Extrema and order statistics are read off LDS dumps of the sorted registers by one lane per sequence; the
+//   all-rows columns are parked in LDS as they get ready (the kernel has no register to spare: 256 per lane, no spill).
+// Which light curves come here is decided by stat_plan_kernel (lcfe.hip) from the rows per band; a light curve whose
+// rows turn out not to ascend in time is appended to the general kernel's list.  Same arithmetic per element as
+// stat.hpp (two-pass moments, exact counts, numpy's percentile interpolation, exact MAD); the sums are associated
+// differently, and the slope quotients go through the reciprocal (stat_slope).
 #pragma once
 #include <utility>
 #include "stat.hpp"
@@ -163,10 +167,11 @@ __device__ __forceinline__ void lanes_order_stats(const double* buf, int base, i
 __device__ __forceinline__ double lanes_pair(double x) { return lane_xor_fetch<1>(x); }
 __device__ __forceinline__ int lanes_pair(int x) { return lane_xor_fetch<1>(x); }
 
-// Eight light curves (one per 8-lane group: `obj` < 0 = none; CSR rows [s1, e1)) -> their 123 columns, or the general
-// kernel's list.  ITERS = rows / 8 a light curve of the tier may have.  Lane j of a group holds rows j, j + 8, ... of its
-// light curve (t, f, e, band code; 256 = no row -- 255 is a band code a file may hold) in registers from ONE round of
-// loads.  Not inlined: the caller's loop state stays out of this function's register budget.
+// Eight light curves (one per 8-lane group: `obj` < 0 = none; CSR rows [s1, e1)) -> their 123 columns, or list
+// `fallback_list`.  ITERS = rows / 8 a light curve of the list may have (band code 256 = no row -- 255 is a code a file
+// may hold).  The rows are loaded in predicated blocks of four trips: one basic block of unconditional loads, a
+// persistent batch loop around this function, or exec-masked element loops all made the compiler spill hundreds of
+// registers (profiles/r02_stat_instruction_budget.md).
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double* gf, const double* ge, const uint8_t* gb, int obj,
                                               int64_t s1, int64_t e1, double* buf, double* all_rows, double* out, int ld, int col0,
@@ -175,8 +180,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     constexpr int STRIDE = StatLanesLds<CAP>::STRIDE;
     constexpr int BLK = 4;
     static_assert(ITERS % BLK == 0 && ITERS <= CAP, "rows per lane");
-    const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7, g8 = g << 3;
-    (void)g;
+    const int lane = threadIdx.x & 63, j = lane & 7, g8 = lane & 56;
     const int n = (int)(e1 - s1);
     const bool has_obj = obj >= 0;
     bool fit = has_obj && n >= 1 && n <= 8 * ITERS;
@@ -504,7 +508,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     }
 
     // ---- the 123 columns of every light curve -> LDS rows -> global
-    double* o = buf + g * 128;
+    double* o = buf + (g8 >> 3) * 128;
     if (fit) {
         if (!split || first) {
             double* ob = o + 17 * band;
