@@ -34,7 +34,6 @@
 #include <utility>
 #include "stat.hpp"
 
-#if defined(__HIPCC__)
 namespace lcfe {
 
 // Batcher's odd-even merge sort for N = 2^k keys as a compile-time list of compare-exchanges
@@ -57,6 +56,11 @@ struct OddEvenNet {
 };
 template <int N>
 inline constexpr OddEvenNet<N> kOddEvenNet{};
+
+}  // namespace lcfe
+
+#if defined(__HIPCC__)
+namespace lcfe {
 
 template <int N, int A, int B>
 __device__ __forceinline__ void reg_exchange(double (&w)[N]) {
