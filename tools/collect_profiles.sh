@@ -20,4 +20,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 for c in FETCH_SIZE WRITE_SIZE; do
   LCFE_SERIAL=1 rocprofv3 --pmc $c --output-format csv -d $O/gp_$c -- python3 bench.py --sets gp2d --steps 1 --warmup 0 --no-cpu-baseline --objects 20000 > /dev/null 2> $O/gp_$c.err && copy_csv $O/gp_$c counter_collection $O/${R}_gp_pmc_$(echo $c | tr A-Z a-z).csv
 done
+# (e) fit and GP kernels: VALU / MFMA occupancy and wait counters on a 20,000-object batch
+LCFE_SERIAL=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $O/fits_sq -- python3 bench.py --sets bazin,powerlaw --steps 1 --warmup 0 --no-cpu-baseline --objects 20000 > /dev/null 2> $O/fits_sq.err && copy_csv $O/fits_sq counter_collection $O/${R}_fits_pmc_sq.csv
+LCFE_SERIAL=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $O/gp_sq -- python3 bench.py --sets gp2d --steps 1 --warmup 0 --no-cpu-baseline --objects 20000 > /dev/null 2> $O/gp_sq.err && copy_csv $O/gp_sq counter_collection $O/${R}_gp_pmc_sq.csv
 ls -la $O/*.csv $O/*.json
