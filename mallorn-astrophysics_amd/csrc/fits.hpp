@@ -42,6 +42,21 @@ struct BazinModel {
         const double denominator = 1.0 + exp(-(t - p[1]) / p[2]);
         return p[0] * numerator / denominator + p[4];
     }
+    // The finite-difference Jacobian evaluates the model at x + h e_k for k = 0..4 (trf.hpp::trf_jacobian).  The two
+    // exponentials of a row depend on (t0, tau_fall) resp. (t0, tau_rise) only, so a step in A or B leaves both and a
+    // step in one time scale leaves one of them bit for bit what they are at x: six exponentials per row instead of
+    // ten, the same values as operator() gives.
+    static constexpr bool kSharedTerms = true;
+    struct Terms { double numerator, denominator; };
+    LCFE_FN Terms terms(double t, const Vec<5>& p) const {
+        return Terms{exp(-(t - p[1]) / p[3]), 1.0 + exp(-(t - p[1]) / p[2])};
+    }
+    template <int K>
+    LCFE_FN double stepped(double t, const Vec<5>& p1, const Terms& at_x) const {
+        const double numerator = (K == 1 || K == 3) ? exp(-(t - p1[1]) / p1[3]) : at_x.numerator;
+        const double denominator = (K == 1 || K == 2) ? 1.0 + exp(-(t - p1[1]) / p1[2]) : at_x.denominator;
+        return p1[0] * numerator / denominator + p1[4];
+    }
 };
 
 // The six band fits of one light curve share one pool: band k (rows boff[k]..boff[k+1]) owns the

@@ -473,6 +473,39 @@ LCFE_FN void trf_residual(const Model& model, const double* t, const double* y, 
     finite = W::all(ok);
 }
 
+// _numdiff.py:146-179 absolute step of component k; :13-64 one-sided bound adjustment
+template <int N>
+LCFE_FN double trf_fd_step(const Vec<N>& xx, const Vec<N>& lb, const Vec<N>& ub, int k) {
+    double h = TRF_SQRT_EPS * ((xx[k] >= 0) ? 1.0 : -1.0) * fmax(1.0, fabs(xx[k]));
+    const double lower = xx[k] - lb[k], upper = ub[k] - xx[k];
+    const double xt = xx[k] + h;
+    const bool violated = (xt < lb[k]) || (xt > ub[k]);
+    const bool fitting = fabs(h) <= fmax(lower, upper);
+    if (violated && fitting) h = -h;
+    if (!fitting) h = (upper >= lower) ? upper : -lower;
+    return h;
+}
+
+// does the model say which of its terms a step in one component leaves untouched (BazinModel)?
+template <class Model, class = void>
+struct trf_shares_terms { static constexpr bool value = false; };
+template <class Model>
+struct trf_shares_terms<Model, decltype((void)Model::kSharedTerms)> { static constexpr bool value = Model::kSharedTerms; };
+
+// one row of the FD Jacobian, components K .. N-1
+template <class Model, class Store, int N, int K, class Terms>
+LCFE_FN void trf_jacobian_row(const Model& model, double ti, double yi, double wi, double ri, int i, const Vec<N> (&x1)[N],
+                              const double (&dx)[N], const Terms& at_x, Store& S, double (&gacc)[N], bool& ok) {
+    if constexpr (K < N) {
+        const double f1 = wi * (model.template stepped<K>(ti, x1[K], at_x) - yi);
+        const double jv = (f1 - ri) / dx[K];
+        S.A[K][i] = jv;
+        ok = ok && finite_d(jv);
+        gacc[K] += jv * ri;
+        trf_jacobian_row<Model, Store, N, K + 1>(model, ti, yi, wi, ri, i, x1, dx, at_x, S, gacc, ok);
+    }
+}
+
 // FD Jacobian into S.A columns (unscaled), returns g = J^T f and a finiteness flag
 template <class W, class Model, class Store>
 LCFE_FN void trf_jacobian(const Model& model, const double* t, const double* y, int m, Store& S, const Vec<Model::NP>& xx,
@@ -481,28 +514,41 @@ LCFE_FN void trf_jacobian(const Model& model, const double* t, const double* y, 
     const int lane = W::lane();
     bool ok = true;
     double gacc[N];
+    if constexpr (trf_shares_terms<Model>::value) {
+        // rows outside, components inside: the terms of the model that a step in component k does not touch are
+        // taken from the row's evaluation at x (same values, same arithmetic, same order of the sums over the rows)
+        Vec<N> x1[N];
+        double dx[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        // _numdiff.py:146-179 absolute step; :13-64 one-sided bound adjustment
-        double h = TRF_SQRT_EPS * ((xx[k] >= 0) ? 1.0 : -1.0) * fmax(1.0, fabs(xx[k]));
-        const double lower = xx[k] - lb[k], upper = ub[k] - xx[k];
-        const double xt = xx[k] + h;
-        const bool violated = (xt < lb[k]) || (xt > ub[k]);
-        const bool fitting = fabs(h) <= fmax(lower, upper);
-        if (violated && fitting) h = -h;
-        if (!fitting) h = (upper >= lower) ? upper : -lower;
-        Vec<N> x1 = xx;
-        x1[k] = xx[k] + h;
-        const double dx = x1[k] - xx[k];
-        double ga = 0;
-        for (int i = lane; i < m; i += W::LANES) {
-            const double f1 = S.w[i] * (model(t[i], x1) - y[i]);
-            const double jv = (f1 - S.r[i]) / dx;
-            S.A[k][i] = jv;
-            ok = ok && finite_d(jv);
-            ga += jv * S.r[i];
+        for (int k = 0; k < N; ++k) {
+            const double h = trf_fd_step<N>(xx, lb, ub, k);
+            x1[k] = xx;
+            x1[k][k] = xx[k] + h;
+            dx[k] = x1[k][k] - xx[k];
+            gacc[k] = 0;
         }
-        gacc[k] = ga;
+        for (int i = lane; i < m; i += W::LANES) {
+            const double ti = t[i], yi = y[i], wi = S.w[i], ri = S.r[i];
+            const auto at_x = model.terms(ti, xx);
+            trf_jacobian_row<Model, Store, N, 0>(model, ti, yi, wi, ri, i, x1, dx, at_x, S, gacc, ok);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double h = trf_fd_step<N>(xx, lb, ub, k);
+            Vec<N> x1 = xx;
+            x1[k] = xx[k] + h;
+            const double dx = x1[k] - xx[k];
+            double ga = 0;
+            for (int i = lane; i < m; i += W::LANES) {
+                const double f1 = S.w[i] * (model(t[i], x1) - y[i]);
+                const double jv = (f1 - S.r[i]) / dx;
+                S.A[k][i] = jv;
+                ok = ok && finite_d(jv);
+                ga += jv * S.r[i];
+            }
+            gacc[k] = ga;
+        }
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) g[k] = W::sum(gacc[k]);
