@@ -44,17 +44,19 @@ struct BazinModel {
     }
     // The finite-difference Jacobian evaluates the model at x + h e_k for k = 0..4 (trf.hpp::trf_jacobian).  The two
     // exponentials of a row depend on (t0, tau_fall) resp. (t0, tau_rise) only, so a step in A or B leaves both and a
-    // step in one time scale leaves one of them bit for bit what they are at x: six exponentials per row instead of
-    // ten, the same values as operator() gives.
-    static constexpr bool kSharedTerms = true;
-    struct Terms { double numerator, denominator; };
-    LCFE_FN Terms terms(double t, const Vec<5>& p) const {
-        return Terms{exp(-(t - p[1]) / p[3]), 1.0 + exp(-(t - p[1]) / p[2])};
+    // step in one time scale leaves one of them bit for bit what they are at x -- and those were computed by the
+    // residual evaluation at x that precedes every Jacobian (kept in the matrix columns the QR has left free): four
+    // exponentials per row instead of ten, the same values as operator() gives.
+    static constexpr int kSharedTerms = 2;
+    LCFE_FN void terms(double t, const Vec<5>& p, double (&q)[2]) const {
+        q[0] = exp(-(t - p[1]) / p[3]);
+        q[1] = 1.0 + exp(-(t - p[1]) / p[2]);
     }
+    LCFE_FN double value(const Vec<5>& p, const double (&q)[2]) const { return p[0] * q[0] / q[1] + p[4]; }
     template <int K>
-    LCFE_FN double stepped(double t, const Vec<5>& p1, const Terms& at_x) const {
-        const double numerator = (K == 1 || K == 3) ? exp(-(t - p1[1]) / p1[3]) : at_x.numerator;
-        const double denominator = (K == 1 || K == 2) ? 1.0 + exp(-(t - p1[1]) / p1[2]) : at_x.denominator;
+    LCFE_FN double stepped(double t, const Vec<5>& p1, const double (&at_x)[2]) const {
+        const double numerator = (K == 1 || K == 3) ? exp(-(t - p1[1]) / p1[3]) : at_x[0];
+        const double denominator = (K == 1 || K == 2) ? 1.0 + exp(-(t - p1[1]) / p1[2]) : at_x[1];
         return p1[0] * numerator / denominator + p1[4];
     }
 };
@@ -210,6 +212,14 @@ struct PowerModel {            // A * max(t - t0, 0.1)^p     x = (A, t0)
     static constexpr int NP = 2;
     double p;
     LCFE_FN double operator()(double t, const Vec<2>& x) const { return x[0] * pow(fmax(t - x[1], 0.1), p); }
+    // a step in A leaves the power bit for bit what the residual evaluation at x computed (see BazinModel)
+    static constexpr int kSharedTerms = 1;
+    LCFE_FN void terms(double t, const Vec<2>& x, double (&q)[1]) const { q[0] = pow(fmax(t - x[1], 0.1), p); }
+    LCFE_FN double value(const Vec<2>& x, const double (&q)[1]) const { return x[0] * q[0]; }
+    template <int K>
+    LCFE_FN double stepped(double t, const Vec<2>& x1, const double (&at_x)[1]) const {
+        return x1[0] * ((K == 1) ? pow(fmax(t - x1[1], 0.1), p) : at_x[0]);
+    }
 };
 struct ExpModel {              // A * exp(-max(t - t0, 0) / tau)   x = (A, tau, t0)
     static constexpr int NP = 3;

@@ -458,13 +458,31 @@ struct TrfState {
     TrfResult res;
 };
 
+// how many terms of its value a model keeps from the residual evaluation at x for the Jacobian at x (0: none)
+template <class Model, class = void>
+struct trf_shared_terms { static constexpr int value = 0; };
+template <class Model>
+struct trf_shared_terms<Model, decltype((void)Model::kSharedTerms)> { static constexpr int value = Model::kSharedTerms; };
+
 template <class W, class Model, class Store>
 LCFE_FN void trf_residual(const Model& model, const double* t, const double* y, int m, Store& S, const Vec<Model::NP>& xx,
                           double* out, double& cost2, bool& finite) {
     double c = 0;
     bool ok = true;
     for (int i = W::lane(); i < m; i += W::LANES) {
-        const double v = S.w[i] * (model(t[i], xx) - y[i]);
+        double mv;
+        if constexpr (trf_shared_terms<Model>::value > 0) {
+            // the terms of the model at xx stay in the first matrix columns (free between the QR and the next Jacobian)
+            // for the Jacobian that follows an accepted point; the value is operator()'s, term by term
+            double q[trf_shared_terms<Model>::value];
+            model.terms(t[i], xx, q);
+#pragma unroll
+            for (int k = 0; k < trf_shared_terms<Model>::value; ++k) S.A[k][i] = q[k];
+            mv = model.value(xx, q);
+        } else {
+            mv = model(t[i], xx);
+        }
+        const double v = S.w[i] * (mv - y[i]);
         out[i] = v;
         ok = ok && finite_d(v);
         c += v * v;
@@ -486,16 +504,10 @@ LCFE_FN double trf_fd_step(const Vec<N>& xx, const Vec<N>& lb, const Vec<N>& ub,
     return h;
 }
 
-// does the model say which of its terms a step in one component leaves untouched (BazinModel)?
-template <class Model, class = void>
-struct trf_shares_terms { static constexpr bool value = false; };
-template <class Model>
-struct trf_shares_terms<Model, decltype((void)Model::kSharedTerms)> { static constexpr bool value = Model::kSharedTerms; };
-
 // one row of the FD Jacobian, components K .. N-1
-template <class Model, class Store, int N, int K, class Terms>
+template <class Model, class Store, int N, int K, int NT>
 LCFE_FN void trf_jacobian_row(const Model& model, double ti, double yi, double wi, double ri, int i, const Vec<N> (&x1)[N],
-                              const double (&dx)[N], const Terms& at_x, Store& S, double (&gacc)[N], bool& ok) {
+                              const double (&dx)[N], const double (&at_x)[NT], Store& S, double (&gacc)[N], bool& ok) {
     if constexpr (K < N) {
         const double f1 = wi * (model.template stepped<K>(ti, x1[K], at_x) - yi);
         const double jv = (f1 - ri) / dx[K];
@@ -514,9 +526,11 @@ LCFE_FN void trf_jacobian(const Model& model, const double* t, const double* y, 
     const int lane = W::lane();
     bool ok = true;
     double gacc[N];
-    if constexpr (trf_shares_terms<Model>::value) {
-        // rows outside, components inside: the terms of the model that a step in component k does not touch are
-        // taken from the row's evaluation at x (same values, same arithmetic, same order of the sums over the rows)
+    if constexpr (trf_shared_terms<Model>::value > 0) {
+        // rows outside, components inside: the terms of the model that a step in component k does not touch are the
+        // ones the residual evaluation at x left in the first matrix columns (same values, same arithmetic, same
+        // order of the sums over the rows).  Every Jacobian follows a residual evaluation at the same x: the start
+        // (trf_begin) and an accepted trial point (trf_inner).
         Vec<N> x1[N];
         double dx[N];
 #pragma unroll
@@ -529,7 +543,9 @@ LCFE_FN void trf_jacobian(const Model& model, const double* t, const double* y, 
         }
         for (int i = lane; i < m; i += W::LANES) {
             const double ti = t[i], yi = y[i], wi = S.w[i], ri = S.r[i];
-            const auto at_x = model.terms(ti, xx);
+            double at_x[trf_shared_terms<Model>::value];
+#pragma unroll
+            for (int k = 0; k < trf_shared_terms<Model>::value; ++k) at_x[k] = S.A[k][i];
             trf_jacobian_row<Model, Store, N, 0>(model, ti, yi, wi, ri, i, x1, dx, at_x, S, gacc, ok);
         }
     } else {
