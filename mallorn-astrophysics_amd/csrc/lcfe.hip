@@ -19,6 +19,7 @@
 #include "feature_sets.hpp"
 #include "stat_lean.hpp"
 #include "stat_lanes.hpp"
+#include "stat_lanes16.hpp"
 #include "gp1d.hpp"
 
 using namespace lcfe;
@@ -71,7 +72,7 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 8;
+constexpr int kNumLists = 2 * kNumBins + 11;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
@@ -79,6 +80,9 @@ constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light cu
 constexpr int kStatL16List = 2 * kNumBins + 5;        // light curves of up to 128 rows whose bands fit 16-row lanes (r, i: 32 rows)
 constexpr int kStatL32List = 2 * kNumBins + 6;        // ... 32-row lanes (r, i: 64 rows)
 constexpr int kStatL32xList = 2 * kNumBins + 7;       // light curves of up to 256 rows whose bands fit 32-row lanes
+constexpr int kStatW16List = 2 * kNumBins + 8;        // ... up to 256 rows, 32-row lanes with 16 lanes per light curve (bands of up to 64 rows, r, i: 128)
+constexpr int kStatW32List = 2 * kNumBins + 9;        // ... up to 512 rows, the same
+constexpr int kStatRetry2List = 2 * kNumBins + 10;    // light curves of the 512-row tier the lanes kernels do not take
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -274,18 +278,32 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
 
 // Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp: CAP = rows of u, g, z, y a lane
 // holds -- r and i: 2 CAP over two lanes; ITERS = rows / 8 of the light curve).  One workgroup = one batch of eight
-// consecutive entries of one of the three lists the plan kernels fill: 32-row lanes for light curves of up to 256
-// rows, 32- and 16-row lanes for those of up to 128 rows.  The lists' lengths are known on the device only; the grid
-// covers n_obj / 8 + 3 batches and the workgroups behind the last batch leave at once.  A light curve whose rows turn
+// consecutive entries of one of the lists the plan kernels fill: 32-row lanes for light curves of up to 256 rows, 32-
+// and 16-row lanes for those of up to 128 rows -- or one batch of FOUR entries of the two lists of light curves with
+// longer bands (stat_lanes16.hpp: 16 lanes per light curve, up to 256 resp. 512 rows).  The lists' lengths are known
+// on the device only; the grid covers n_obj / 4 + 6 batches and the workgroups behind the last batch leave at once.  A light curve whose rows turn
 // out not to ascend in time is appended to list `retry`.
 __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
     __shared__ StatLanesLds<32> L;
     const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List], c32x = bins.counts[kStatL32xList];
-    const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3, nb32x = (c32x + 7) >> 3;
-    const int b = (int)blockIdx.x;
+    const int cw16 = bins.counts[kStatW16List], cw32 = bins.counts[kStatW32List];
+    const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3, nb32x = (c32x + 7) >> 3, nbw16 = (cw16 + 3) >> 2, nbw32 = (cw32 + 3) >> 2;
+    int b = (int)blockIdx.x;
     int* rl = bins.lists + (int64_t)retry * bins.stride;
     int* rc = &bins.counts[retry];
     // (the long batches first: they are the ones whose tail would otherwise stick out)
+    if (b < nbw32) {
+        stat_lanes16_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW32List * bins.stride, cw32, b, L.buf,
+                                 L.all_rows, out, ld, col0, rl, rc);
+        return;
+    }
+    b -= nbw32;
+    if (b < nbw16) {
+        stat_lanes16_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW16List * bins.stride, cw16, b, L.buf,
+                                 L.all_rows, out, ld, col0, rl, rc);
+        return;
+    }
+    b -= nbw16;
     if (b < nb32x)
         stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, L.buf, L.all_rows, out, ld,
                                col0, rl, rc);
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins
 // curve whose bands do not fit the lanes is appended to list `unfit` (a one-light-curve-per-wavefront kernel takes it).
 constexpr int kPlanThreads = 1024;
 template <int ITERS>
-__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int dst16, int dst32, int unfit) {
+__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int t0, int dst0, int t1, int dst1, int unfit) {
     __shared__ int wcount[kPlanThreads / 64][3];
     __shared__ int base[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7;
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
     eff = ((cnt[2] + 1) / 2 > eff) ? (cnt[2] + 1) / 2 : eff;
     eff = ((cnt[3] + 1) / 2 > eff) ? (cnt[3] + 1) / 2 : eff;
     const bool fits = known && n >= 1 && n <= 8 * ITERS;
-    const int cls = (obj < 0 || j != 0) ? -1 : ((fits && eff <= 16) ? 0 : ((fits && eff <= 32) ? 1 : 2));
+    const int cls = (obj < 0 || j != 0) ? -1 : ((fits && eff <= t0) ? 0 : ((fits && eff <= t1) ? 1 : 2));
     int rank = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
         if (lane == 0) wcount[wave][c] = popcll(m);
     }
     __syncthreads();
-    // (dst16 == dst32 is allowed: the two classes then take consecutive slices of one list)
+    // (dst0 == dst1 is allowed: the two classes then take consecutive slices of one list)
     if (threadIdx.x < 3) {
         int total = 0;
         for (int w = 0; w < kPlanThreads / 64; ++w) {
@@ -362,12 +380,12 @@ __global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bi
             wcount[w][threadIdx.x] = total;
             total += c;
         }
-        const int dst = (threadIdx.x == 0) ? dst16 : ((threadIdx.x == 1) ? dst32 : unfit);
+        const int dst = (threadIdx.x == 0) ? dst0 : ((threadIdx.x == 1) ? dst1 : unfit);
         base[threadIdx.x] = total ? atomicAdd(&bins.counts[dst], total) : 0;
     }
     __syncthreads();
     if (cls >= 0) {
-        const int dst = (cls == 0) ? dst16 : ((cls == 1) ? dst32 : unfit);
+        const int dst = (cls == 0) ? dst0 : ((cls == 1) ? dst1 : unfit);
         bins.lists[(int64_t)dst * bins.stride + base[cls] + wcount[wave][cls] + rank] = obj;
     }
 }
@@ -1298,16 +1316,16 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
 }
 
 template <int ITERS>
-int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int dst16, int dst32, int unfit, hipStream_t stream) {
+int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int t0, int dst0, int t1, int dst1, int unfit, hipStream_t stream) {
     const int64_t grid = (B.n_obj + kPlanThreads / 8 - 1) / (kPlanThreads / 8);
     if (grid < 1) return 0;
-    hipLaunchKernelGGL(stat_plan_kernel<ITERS>, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, dst16, dst32, unfit);
+    hipLaunchKernelGGL(stat_plan_kernel<ITERS>, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, t0, dst0, t1, dst1, unfit);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_stat_lanes_all(const BatchView& B, const Bins& bins, int retry, double* out, int ld, int col0, hipStream_t stream) {
-    const int64_t grid = (B.n_obj + 7) / 8 + 3;
+    const int64_t grid = (B.n_obj + 3) / 4 + 6;
     hipLaunchKernelGGL(stat_lanes_all_kernel, dim3((unsigned)grid), dim3(64), 0, stream, B, bins, retry, out, ld, col0);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1345,7 +1363,7 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
         int rc = 0;
         switch (ti) {
-            case 2: rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q_long, dev, tk + ti); break;
+            case 2: if (!lanes) rc = launch_stat_lean<512>(B, bins, ti, out, ld, col0, q_long, dev, tk + ti); break;   // (else: after its plan kernel)
             case 3: rc = launch_tier<SET_STAT, 1024>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q_long, dev, tk + ti); break;
             case 4: rc = launch_tier<SET_STAT, 2048>(B, bins, ti, nan_from, out, ld, col0, nullptr, 0, 0, q_long, dev, tk + ti); break;
         }
@@ -1355,22 +1373,28 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     if (lanes) {
         // light curves of the 128-row tier the lanes kernels cannot take join the 256-row tier's list when that tier
         // runs, else a list of their own
-        int rc = launch_stat_plan<16>(B, bins, 0, kStatL16List, kStatL32List, (last >= 1) ? 1 : kStatRetryList, stream);
-        // the 256-row tier (and what the 128-row tier handed over): 32-row lanes, or the one-light-curve-per-wavefront kernel
-        if (!rc && last >= 1) rc = launch_stat_plan<32>(B, bins, 1, kStatL32xList, kStatL32xList, kStatRetryList + 1, stream);
+        // (the threshold is on the rows of u, g, z, y and half the rows of r, i: what an 8-lane group's lanes must hold)
+        int rc = launch_stat_plan<16>(B, bins, 0, 16, kStatL16List, 32, kStatL32List, (last >= 1) ? 1 : kStatRetryList, stream);
+        // the 256-row tier (and what the 128-row tier handed over): 32-row lanes with 8 or with 16 lanes per light curve; what
+        // fits neither (a band of more than 64 rows, r / i 128) goes with the 512-row tier's leftovers when that tier runs
+        if (!rc && last >= 1) rc = launch_stat_plan<32>(B, bins, 1, 32, kStatL32xList, 64, kStatW16List, (last >= 2) ? kStatRetry2List : kStatRetryList + 1, stream);
+        // the 512-row tier: 32-row lanes with 16 lanes per light curve, or the one-light-curve-per-wavefront kernel
+        if (!rc && last >= 2) rc = launch_stat_plan<64>(B, bins, 2, 64, kStatW32List, 64, kStatW32List, kStatRetry2List, stream);
         if (rc) return rc;
-        *n_launch += 2;
+        *n_launch += 3;
     }
     if (fork) {
         HIP_TRY(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_plan, stream));
         HIP_TRY(hipStreamWaitEvent(s1, ev_plan, 0));
+        if (lanes && last >= 2) HIP_TRY(hipStreamWaitEvent(s2, ev_plan, 0));
     }
     {
         int rc = 0;
         if (lanes) {
             // a light curve whose rows turn out not to ascend in time goes to the general kernel's list
-            if (last >= 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q_mid, dev, tk + 1);
+            if (last >= 2) rc = launch_stat_lean<512>(B, bins, kStatRetry2List, out, ld, col0, q_long, dev, tk + 2);
+            if (!rc && last == 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q_mid, dev, tk + 1, 512);
             if (!rc) rc = launch_stat_lanes_all(B, bins, kStatFallbackList, out, ld, col0, stream);
             if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, stream, dev, tk + 6, 512);
             *n_launch += 2;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void lane_merge(double (&w)[N], int lane_in_group) {
             w[N - 1 - r] = ((p2 < w[N - 1 - r]) == keep_min) ? p2 : w[N - 1 - r];
         }
     }
+    if constexpr (D >= 8) lane_half_cleaner<N, 4>(w, (lane_in_group & 4) == 0);
     if constexpr (D >= 4) lane_half_cleaner<N, 2>(w, (lane_in_group & 2) == 0);
     if constexpr (D >= 2) lane_half_cleaner<N, 1>(w, (lane_in_group & 1) == 0);
     reg_half_cleaners<N, N / 2>(w);
