@@ -107,8 +107,9 @@ def test_statistics_band_shapes():
 
 
 def test_statistics_lane_routes():
-    """The eight-light-curves-per-wavefront statistics kernels (stat_lanes.hpp): band lengths on both sides of every
-    routing threshold of the plan kernel (16- / 32-row lanes, r and i split over two lanes, 128 / 256 rows), bands of
+    """The eight- and four-light-curves-per-wavefront statistics kernels (stat_lanes.hpp, stat_lanes16.hpp): band lengths
+    on both sides of every routing threshold of the plan kernels (16- / 32-row lanes, 8 / 16 lanes per light curve, r and i
+    over two / four lanes, 128 / 256 / 512 rows), bands of
     0 / 1 / 2 rows, odd and even r / i halves, negative and zero times, NaN and inf fluxes in either half, rows out of
     time order and unknown band codes inside lane-eligible light curves, and batch lengths that do not fill the last
     group of eight -- each object against the oracle, and the batch in a different order."""
@@ -141,6 +142,17 @@ def test_statistics_lane_routes():
               [3, 9, 31, 30, 20, 7], [10, 20, 41, 40, 30, 12], [4, 4, 64, 4, 4, 4], [4, 4, 4, 64, 4, 48],
               [8, 8, 40, 40, 16, 16], [20, 20, 20, 20, 24, 24], [30, 30, 60, 60, 30, 30], [12, 12, 48, 47, 5, 5]):
         add(c)
+    # 16 lanes per light curve (stat_lanes16.hpp): bands of up to 64 rows (r, i: 128) in up to 512 rows, on both sides
+    # of the thresholds, four-part splits with uneven parts, parts that stay empty
+    for c in ([64, 64, 128, 128, 64, 64], [65, 64, 128, 128, 64, 63], [64, 64, 129, 127, 64, 64], [33, 10, 70, 75, 40, 12],
+              [10, 10, 101, 99, 10, 10], [1, 0, 97, 3, 33, 2], [40, 0, 0, 0, 0, 41], [0, 0, 5, 0, 0, 33], [60, 60, 60, 60, 8, 8],
+              [50, 50, 100, 100, 50, 50], [34, 34, 66, 66, 34, 22]):
+        add(c)
+    add([33, 10, 70, 75, 40, 12], nan_band=2)
+    add([33, 10, 70, 75, 40, 12], nan_band=4, inf_band=3)
+    add([50, 50, 100, 100, 50, 50], nan_band=3)
+    add([50, 50, 100, 100, 50, 50], t0=-100.0, dup_t=True)
+    add([50, 50, 100, 100, 50, 50], shuffle=True)         # general kernel
     add([10, 10, 30, 30, 10, 10], t0=-250.0)              # times around zero: slots behind a lane's rows hold 0.0
     add([10, 10, 30, 30, 10, 10], t0=0.0)
     add([6, 6, 21, 20, 6, 6], nan_band=2)
