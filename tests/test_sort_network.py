@@ -1,63 +1,87 @@
-"""The compile-time sorting network of the statistics lanes kernels (csrc/stat_lanes.hpp: Batcher's odd-even merge
-sort as a list of compare-exchanges) checked on the CPU: the list is generated by the same constexpr code the device
-build uses, printed by a small host program, and must sort -- all 2^16 zero-one inputs for 16 keys (the 0-1 principle
-makes that a proof), random and adversarial inputs for 32 and 64 keys -- with Batcher's exchange counts."""
-import os
-import subprocess
-import tempfile
-
+"""The wiring of the register sorting network of csrc/stage.hpp (sort_flip_step / sort_half_steps /
+sort_merges), re-stated lane by lane in numpy: the same partner masks, register pairings and
+keep-min rules must sort every input for every (lanes, values-per-lane) shape the kernels
+instantiate.  (The device code itself is exercised by the GPU parity tests; this pins the design.)"""
 import numpy as np
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = r'''
-#include <cstdio>
-#include "stat_lanes.hpp"
-template <int N> void dump() {
-    constexpr lcfe::OddEvenNet<N> net{};
-    std::printf("%d %d", N, net.count);
-    for (int c = 0; c < net.count; ++c) std::printf(" %d %d", (int)net.a[c], (int)net.b[c]);
-    std::printf("\n");
-}
-int main() { dump<16>(); dump<32>(); dump<64>(); return 0; }
-'''
+import pytest
 
 
-def _networks():
-    with tempfile.TemporaryDirectory() as d:
-        src, exe = os.path.join(d, "net.cpp"), os.path.join(d, "net")
-        open(src, "w").write(SRC)
-        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "mallorn-astrophysics_amd", "csrc"), src, "-o", exe],
-                       check=True)
-        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    nets = {}
-    for line in out.strip().split("\n"):
-        v = list(map(int, line.split()))
-        nets[v[0]] = np.array(v[2:], dtype=np.int64).reshape(v[1], 2)
-    return nets
+def network_sort(values, lanes, kpl):
+    """values: [lanes, kpl] array, element index = lane * kpl + r (stage.hpp blocked layout)."""
+    v = np.array(values, dtype=float).reshape(lanes, kpl).copy()
+    lane = np.arange(lanes)
+
+    def flip(k):
+        if k <= kpl:                                           # partners inside a lane: r ^ (k - 1)
+            for r in range(kpl):
+                q = r ^ (k - 1)
+                if r < q:
+                    a, b = v[:, r].copy(), v[:, q].copy()
+                    v[:, r], v[:, q] = np.minimum(a, b), np.maximum(a, b)
+        else:
+            ml = k // kpl - 1                                  # lane ^ ml, register kpl - 1 - r
+            keep_min = (lane & ((ml + 1) >> 1)) == 0
+            p = np.stack([v[lane ^ ml, kpl - 1 - r] for r in range(kpl)], axis=1)
+            lo, hi = np.minimum(v, p), np.maximum(v, p)
+            v[:] = np.where(keep_min[:, None], lo, hi)
+
+    def half(j):
+        while j >= 1:
+            if j < kpl:
+                for r in range(kpl):
+                    if (r & j) == 0:
+                        a, b = v[:, r].copy(), v[:, r | j].copy()
+                        v[:, r], v[:, r | j] = np.minimum(a, b), np.maximum(a, b)
+            else:
+                ml = j // kpl
+                keep_min = (lane & ml) == 0
+                p = v[lane ^ ml, :]
+                lo, hi = np.minimum(v, p), np.maximum(v, p)
+                v[:] = np.where(keep_min[:, None], lo, hi)
+            j //= 2
+
+    k = 2
+    while k <= lanes * kpl:
+        flip(k)
+        half(k // 4)
+        k *= 2
+    return v.reshape(-1)
 
 
-def _apply(net, x):
-    x = x.copy()
-    for a, b in net:
-        lo, hi = np.minimum(x[:, a], x[:, b]), np.maximum(x[:, a], x[:, b])
-        x[:, a], x[:, b] = lo, hi
-    return x
+@pytest.mark.parametrize("lanes,kpl", [(8, 4), (8, 8), (64, 2), (64, 4), (64, 8)])
+def test_network_sorts(lanes, kpl):
+    rng = np.random.default_rng(lanes * 100 + kpl)
+    n = lanes * kpl
+    for trial in range(60):
+        m = int(rng.integers(1, n + 1))
+        x = np.full(n, np.inf)
+        kind = trial % 4
+        if kind == 0:
+            x[:m] = rng.normal(0, 10, m)
+        elif kind == 1:
+            x[:m] = rng.integers(-3, 4, m)                      # many ties, signed zeros
+        elif kind == 2:
+            x[:m] = np.sort(rng.normal(0, 1, m))[::-1]          # reversed
+        else:
+            x[:m] = rng.choice([0.0, 1.0], m)                   # 0-1 inputs (zero-one principle samples)
+        x = x[rng.permutation(n)] if kind != 2 else x
+        got = network_sort(x, lanes, kpl)
+        assert np.array_equal(got, np.sort(x)), (lanes, kpl, trial)
 
 
-def test_odd_even_merge_networks_sort():
-    nets = _networks()
-    assert {n: len(v) for n, v in nets.items()} == {16: 63, 32: 191, 64: 543}
-    for n, net in nets.items():
-        assert (net[:, 0] < net[:, 1]).all() and net.min() >= 0 and net.max() < n
-    # 16 keys: every zero-one input
-    bits = ((np.arange(1 << 16)[:, None] >> np.arange(16)[None, :]) & 1).astype(np.float64)
-    out = _apply(nets[16], bits)
-    assert (np.diff(out, axis=1) >= 0).all()
-    rng = np.random.default_rng(5)
-    for n in (32, 64):
-        x = np.concatenate([rng.normal(size=(4000, n)), rng.integers(0, 3, size=(4000, n)).astype(float),
-                            np.sort(rng.normal(size=(200, n)), axis=1)[:, ::-1],
-                            (rng.random((20000, n)) < rng.random((20000, 1))).astype(float)])
-        x[::7, rng.integers(0, n, 5)] = np.inf          # the padding value of the kernels
-        out = _apply(nets[n], x)
-        assert np.array_equal(out, np.sort(x, axis=1))
+def test_xor_partner_patterns_used_by_the_device_code():
+    """Every cross-lane mask the network needs is one the device fetch implements: DPP for 1, 2, 3, 7,
+    8, 15, ds_swizzle below 32, ds_bpermute for 32..63 (wave.hpp lane_xor_fetch)."""
+    for lanes, kpl in [(8, 4), (8, 8), (64, 2), (64, 4), (64, 8)]:
+        masks = set()
+        k = 2
+        while k <= lanes * kpl:
+            if k > kpl:
+                masks.add(k // kpl - 1)
+            j = k // 4
+            while j >= 1:
+                if j >= kpl:
+                    masks.add(j // kpl)
+                j //= 2
+            k *= 2
+        assert all(0 < m < lanes for m in masks), (lanes, kpl, masks)
