@@ -72,17 +72,16 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 11;
+constexpr int kNumLists = 2 * kNumBins + 9;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
-constexpr int kStatRetryList = 2 * kNumBins + 3;      // + tier (0, 1): light curves of the tier the lanes kernels do not take
-constexpr int kStatL16List = 2 * kNumBins + 5;        // light curves of up to 128 rows whose bands fit 16-row lanes (r, i: 32 rows)
-constexpr int kStatL32List = 2 * kNumBins + 6;        // ... 32-row lanes (r, i: 64 rows)
-constexpr int kStatL32xList = 2 * kNumBins + 7;       // light curves of up to 256 rows whose bands fit 32-row lanes
-constexpr int kStatW16List = 2 * kNumBins + 8;        // ... up to 256 rows, 32-row lanes with 16 lanes per light curve (bands of up to 64 rows, r, i: 128)
-constexpr int kStatW32List = 2 * kNumBins + 9;        // ... up to 512 rows, the same
-constexpr int kStatRetry2List = 2 * kNumBins + 10;    // light curves of the 512-row tier the lanes kernels do not take
+constexpr int kStatRetryList = 2 * kNumBins + 3;      // light curves of up to 512 rows the lanes kernels do not take (stat_plan_kernel)
+constexpr int kStatL16List = 2 * kNumBins + 4;        // light curves of up to 128 rows whose bands fit 16-row lanes (r, i: 32 rows)
+constexpr int kStatL32List = 2 * kNumBins + 5;        // ... 32-row lanes (r, i: 64 rows)
+constexpr int kStatL32xList = 2 * kNumBins + 6;       // light curves of up to 256 rows whose bands fit 32-row lanes
+constexpr int kStatW16List = 2 * kNumBins + 7;        // ... up to 256 rows, 32-row lanes with 16 lanes per light curve (bands of up to 64 rows, r, i: 128)
+constexpr int kStatW32List = 2 * kNumBins + 8;        // ... up to 512 rows, the same
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -315,79 +314,108 @@ __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins
                                L.all_rows, out, ld, col0, rl, rc);
 }
 
-// Which lanes kernel takes a light curve of the 128-row tier (list `src`): 8 lanes per light curve count its rows per
-// band (1 byte per row is read); lists are appended per 128-light-curve workgroup with one atomic per list.  A light
-// curve whose bands do not fit the lanes is appended to list `unfit` (a one-light-curve-per-wavefront kernel takes it).
+// Which statistics kernel takes a light curve of up to 512 rows: ONE launch over the three tier lists (128 / 256 / 512
+// rows), 8 lanes per light curve count its rows per band (1 byte per row is read, once) and the light curve is appended
+// to the list of the cheapest lanes variant its bands fit:
+//     rows <= 128   bands <= 16 rows (r, i: 32)   -> kStatL16List   (8 lanes per light curve, 16-row lanes)
+//     rows <= 128   bands <= 32 (64)              -> kStatL32List   (8 lanes, 32-row lanes)
+//     rows <= 256   bands <= 32 (64)              -> kStatL32xList  (8 lanes, 32-row lanes, 32 rows per lane loaded)
+//     rows <= 256   bands <= 64 (128)             -> kStatW16List   (16 lanes per light curve)
+//     rows <= 512   bands <= 64 (128)             -> kStatW32List   (16 lanes per light curve)
+//     anything else (longer bands, unknown band codes, no rows)     -> kStatRetryList (one light curve per wavefront)
+// The lists are private to the statistics set: the tier lists every other set reads are never appended to.  A workgroup
+// takes 128 consecutive entries of one tier list (the long tier first); the lists' lengths are known on the device only,
+// so the grid covers n_obj / 128 + 3 workgroups and the ones behind the last slice leave at once.  Lists are appended
+// per workgroup with one atomic per destination.
 constexpr int kPlanThreads = 1024;
+constexpr int kPlanDst = 6;
 template <int ITERS>
-__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins, int src, int t0, int dst0, int t1, int dst1, int unfit) {
-    __shared__ int wcount[kPlanThreads / 64][3];
-    __shared__ int base[3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7;
-    const int count = bins.counts[src];
-    const int64_t pos = (int64_t)blockIdx.x * (kPlanThreads / 8) + wave * 8 + g;
-    if ((int64_t)blockIdx.x * (kPlanThreads / 8) >= count) return;
-    int obj = -1, n = 0;
-    int64_t s0 = 0;
-    if (pos < count) {
-        obj = bins.lists[(int64_t)src * bins.stride + pos];
-        s0 = B.offsets[obj];
-        n = (int)(B.offsets[obj + 1] - s0);
-    }
-    // the source list holds light curves of up to 8 ITERS rows: ITERS rows per lane, all loads in flight at once
+__device__ __forceinline__ unsigned long long stat_plan_count(const uint8_t* pb, int n, int j, bool& known) {
+    // ITERS rows per lane, all loads in flight at once
     int bb[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int row = it * 8 + j;
-        bb[it] = (row < n) ? (int)B.b[s0 + row] : 256;
+        bb[it] = (row < n) ? (int)pb[row] : 256;
     }
-    // rows per band: six 10-bit counters in one 64-bit word per lane (codes above 5 count in the bits that fall off),
-    // summed over the 8 lanes of the light curve
+    // rows per band: six 10-bit counters in one 64-bit word per lane (codes above 5 count in the bits that fall off)
     unsigned long long acc = 0;
-    bool known = true;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int b = bb[it];
         known = known && (b < 6 || b == 256);
         acc += 1ull << (10 * ((b < 6) ? b : 6));
     }
+    return acc;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void stat_plan_kernel(BatchView B, Bins bins) {
+    __shared__ int wcount[kPlanThreads / 64][kPlanDst];
+    __shared__ int base[kPlanDst];
+    constexpr int PER = kPlanThreads / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, j = lane & 7;
+    const int c0 = bins.counts[0], c1 = bins.counts[1], c2 = bins.counts[2];
+    const int nb2 = (c2 + PER - 1) / PER, nb1 = (c1 + PER - 1) / PER, nb0 = (c0 + PER - 1) / PER;
+    int blk = (int)blockIdx.x, tier, count;
+    if (blk < nb2) { tier = 2; count = c2; }
+    else if (blk < nb2 + nb1) { tier = 1; count = c1; blk -= nb2; }
+    else if (blk < nb2 + nb1 + nb0) { tier = 0; count = c0; blk -= nb2 + nb1; }
+    else return;
+    const int64_t pos = (int64_t)blk * PER + wave * 8 + g;
+    int obj = -1, n = 0;
+    int64_t s0 = 0;
+    if (pos < count) {
+        obj = bins.lists[(int64_t)tier * bins.stride + pos];
+        s0 = B.offsets[obj];
+        n = (int)(B.offsets[obj + 1] - s0);
+    }
+    bool known = true;
+    unsigned long long acc;
+    if (tier == 0) acc = stat_plan_count<16>(B.b + s0, n, j, known);
+    else if (tier == 1) acc = stat_plan_count<32>(B.b + s0, n, j, known);
+    else acc = stat_plan_count<64>(B.b + s0, n, j, known);
     acc = GroupDev<8>::reduce((long long)acc, [](long long x, long long y) { return x + y; });
     int cnt[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) cnt[k] = (int)(acc >> (10 * k)) & 1023;
     known = GroupDev<8>::all(known);
+    // what a lane of an 8-lane group must hold: the rows of u, g, z, y and half the rows of r, i
     int eff = cnt[0];
     eff = (cnt[1] > eff) ? cnt[1] : eff;
     eff = (cnt[4] > eff) ? cnt[4] : eff;
     eff = (cnt[5] > eff) ? cnt[5] : eff;
     eff = ((cnt[2] + 1) / 2 > eff) ? (cnt[2] + 1) / 2 : eff;
     eff = ((cnt[3] + 1) / 2 > eff) ? (cnt[3] + 1) / 2 : eff;
-    const bool fits = known && n >= 1 && n <= 8 * ITERS;
-    const int cls = (obj < 0 || j != 0) ? -1 : ((fits && eff <= t0) ? 0 : ((fits && eff <= t1) ? 1 : 2));
+    const bool fits = known && n >= 1 && n <= 512;
+    int cls = -1;
+    if (obj >= 0 && j == 0) {
+        cls = 5;
+        if (fits && eff <= 64) {
+            if (n <= 128) cls = (eff <= 16) ? 0 : ((eff <= 32) ? 1 : 3);
+            else if (n <= 256) cls = (eff <= 32) ? 2 : 3;
+            else cls = 4;
+        }
+    }
     int rank = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < kPlanDst; ++c) {
         const unsigned long long m = __ballot(cls == c);
         if (cls == c) rank = WaveDev::prefix(m);
         if (lane == 0) wcount[wave][c] = popcll(m);
     }
     __syncthreads();
-    // (dst0 == dst1 is allowed: the two classes then take consecutive slices of one list)
-    if (threadIdx.x < 3) {
+    auto dst_of = [](int c) { return (c == 0) ? kStatL16List : (c == 1) ? kStatL32List : (c == 2) ? kStatL32xList : (c == 3) ? kStatW16List : (c == 4) ? kStatW32List : kStatRetryList; };
+    if (threadIdx.x < kPlanDst) {
         int total = 0;
         for (int w = 0; w < kPlanThreads / 64; ++w) {
             const int c = wcount[w][threadIdx.x];
             wcount[w][threadIdx.x] = total;
             total += c;
         }
-        const int dst = (threadIdx.x == 0) ? dst0 : ((threadIdx.x == 1) ? dst1 : unfit);
-        base[threadIdx.x] = total ? atomicAdd(&bins.counts[dst], total) : 0;
+        base[threadIdx.x] = total ? atomicAdd(&bins.counts[dst_of((int)threadIdx.x)], total) : 0;
     }
     __syncthreads();
-    if (cls >= 0) {
-        const int dst = (cls == 0) ? dst0 : ((cls == 1) ? dst1 : unfit);
-        bins.lists[(int64_t)dst * bins.stride + base[cls] + wcount[wave][cls] + rank] = obj;
-    }
+    if (cls >= 0) bins.lists[(int64_t)dst_of(cls) * bins.stride + base[cls] + wcount[wave][cls] + rank] = obj;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1315,11 +1343,9 @@ int launch_stat_lean(const BatchView& B, const Bins& bins, int bin, double* out,
     return 0;
 }
 
-template <int ITERS>
-int launch_stat_plan(const BatchView& B, const Bins& bins, int src, int t0, int dst0, int t1, int dst1, int unfit, hipStream_t stream) {
-    const int64_t grid = (B.n_obj + kPlanThreads / 8 - 1) / (kPlanThreads / 8);
-    if (grid < 1) return 0;
-    hipLaunchKernelGGL(stat_plan_kernel<ITERS>, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins, src, t0, dst0, t1, dst1, unfit);
+int launch_stat_plan(const BatchView& B, const Bins& bins, hipStream_t stream) {
+    const int64_t grid = (B.n_obj + kPlanThreads / 8 - 1) / (kPlanThreads / 8) + 3;
+    hipLaunchKernelGGL(stat_plan_kernel, dim3((unsigned)grid), dim3(kPlanThreads), 0, stream, B, bins);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1371,17 +1397,10 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
         ++*n_launch;
     }
     if (lanes) {
-        // light curves of the 128-row tier the lanes kernels cannot take join the 256-row tier's list when that tier
-        // runs, else a list of their own
-        // (the threshold is on the rows of u, g, z, y and half the rows of r, i: what an 8-lane group's lanes must hold)
-        int rc = launch_stat_plan<16>(B, bins, 0, 16, kStatL16List, 32, kStatL32List, (last >= 1) ? 1 : kStatRetryList, stream);
-        // the 256-row tier (and what the 128-row tier handed over): 32-row lanes with 8 or with 16 lanes per light curve; what
-        // fits neither (a band of more than 64 rows, r / i 128) goes with the 512-row tier's leftovers when that tier runs
-        if (!rc && last >= 1) rc = launch_stat_plan<32>(B, bins, 1, 32, kStatL32xList, 64, kStatW16List, (last >= 2) ? kStatRetry2List : kStatRetryList + 1, stream);
-        // the 512-row tier: 32-row lanes with 16 lanes per light curve, or the one-light-curve-per-wavefront kernel
-        if (!rc && last >= 2) rc = launch_stat_plan<64>(B, bins, 2, 64, kStatW32List, 64, kStatW32List, kStatRetry2List, stream);
+        // one routing pass over the tiers of up to 512 rows (stat_plan_kernel): lanes lists + the retry list
+        const int rc = launch_stat_plan(B, bins, stream);
         if (rc) return rc;
-        *n_launch += 3;
+        ++*n_launch;
     }
     if (fork) {
         HIP_TRY(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
@@ -1392,9 +1411,10 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     {
         int rc = 0;
         if (lanes) {
+            // what the lanes variants do not take: one light curve per wavefront, sized for the longest tier present;
             // a light curve whose rows turn out not to ascend in time goes to the general kernel's list
-            if (last >= 2) rc = launch_stat_lean<512>(B, bins, kStatRetry2List, out, ld, col0, q_long, dev, tk + 2);
-            if (!rc && last == 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList + 1, out, ld, col0, q_mid, dev, tk + 1, 512);
+            if (last >= 2) rc = launch_stat_lean<512>(B, bins, kStatRetryList, out, ld, col0, q_long, dev, tk + 2);
+            else if (last == 1) rc = launch_stat_lean<256>(B, bins, kStatRetryList, out, ld, col0, q_mid, dev, tk + 1, 512);
             if (!rc) rc = launch_stat_lanes_all(B, bins, kStatFallbackList, out, ld, col0, stream);
             if (!rc && last < 1) rc = launch_stat_lean<128>(B, bins, kStatRetryList, out, ld, col0, stream, dev, tk + 6, 512);
             *n_launch += 2;
@@ -1550,6 +1570,11 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             return fail_msg("lcfe_extract_device: feature set " + std::to_string(s) + " is not built into this library");
     if (n_obj < 0 || n_points < 0 || max_len < 0) return fail_msg("lcfe_extract_device: negative size");
     if (n_obj > 0x7fffffff - kBinThreads) return fail_msg("lcfe_extract_device: more than 2^31 objects in one batch");
+    // fit ids are packed into int32: object * 8 + band (Bazin), object * 32 + band * 9 + model (decline fits)
+    if ((mask & (1 << SET_BAZIN)) && n_obj >= (1ll << 28))
+        return fail_msg("lcfe_extract_device: the Bazin set takes fewer than 2^28 objects per batch (split the batch)");
+    if ((mask & (1 << SET_POWERLAW)) && n_obj >= (1ll << 26))
+        return fail_msg("lcfe_extract_device: the power-law set takes fewer than 2^26 objects per batch (split the batch)");
     if (n_obj == 0) return 0;
     if (!d_offsets || !d_out || (n_points > 0 && (!d_t || !d_flux || !d_err || !d_band)))
         return fail_msg("lcfe_extract_device: null array");

@@ -10,6 +10,8 @@ vector is needed to reassemble the frame.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -27,6 +29,9 @@ def object_costs(offsets, sets=None):
     """Predicted cost of every object for the feature sets `sets` (None = the full v34a/v55 workload)."""
     n = np.diff(np.asarray(offsets, np.int64)).astype(np.float64)
     cost = COST_POINT * n
+    if isinstance(sets, (int, np.integer)):                 # a feature-set mask, as mask_of / DeviceBatch.run accept
+        from .engine import sets_of
+        sets = sets_of(int(sets))
     if sets is None or any(s in GP_SETS for s in ([sets] if isinstance(sets, str) else sets)):
         cost = cost + COST_GP_N2 * n * n + COST_GP_N3 * n * n * n
     return cost
@@ -85,7 +90,8 @@ def gather_rows(local, n_total: int, bounds, group=None, dst: int = 0):
     ncol = local.shape[1]
     buf = local
     if local.shape[0] != pad:
-        buf = torch.full((pad, ncol), float("nan"), dtype=local.dtype, device=local.device)
+        fill = float("nan") if local.dtype.is_floating_point else 0
+        buf = torch.full((pad, ncol), fill, dtype=local.dtype, device=local.device)
         buf[:local.shape[0]] = local
     gl = [torch.empty((pad, ncol), dtype=local.dtype, device=local.device) for _ in range(world)] if rank == dst else None
     dist.gather(buf.contiguous(), gl, dst=dst, group=group)
@@ -97,11 +103,13 @@ def gather_rows(local, n_total: int, bounds, group=None, dst: int = 0):
     return out
 
 
-def extract_sharded(sets, csr, z=None, group=None):
-    """Run feature sets on this rank's shard (on ``cuda:LOCAL_RANK``) and gather to rank 0.
+def extract_sharded(sets, csr, z=None, group=None, return_status=False):
+    """Run feature sets on this rank's shard (on torch's current device) and gather to rank 0.
 
     Every rank passes the SAME full ``csr`` (or at least the same ``offsets``); returns the
-    ``[n_obj, ncols]`` numpy matrix on rank 0 and ``None`` on the other ranks."""
+    ``[n_obj, ncols]`` numpy matrix on rank 0 and ``None`` on the other ranks (with ``return_status`` the pair
+    ``(matrix, status)``; ``status`` is ``None`` for masks without status words).  The collective runs on device
+    tensors with the ``nccl`` backend (RCCL over xGMI) and on host copies with ``gloo``."""
     import torch
     import torch.distributed as dist
 
@@ -109,9 +117,72 @@ def extract_sharded(sets, csr, z=None, group=None):
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    n_obj = len(csr["offsets"]) - 1
     bounds = shard_bounds(csr["offsets"], world, sets)
     sub, sub_z, _ = shard_csr(csr, rank, world, z, sets)
     batch = DeviceBatch(sub, z=sub_z, device=torch.cuda.current_device())
-    out, _ = batch.run(sets)
-    full = gather_rows(out, len(csr["offsets"]) - 1, bounds, group=group)
-    return None if full is None else full.cpu().numpy()
+    out, status = batch.run(sets)
+    host = dist.get_backend(group) == "gloo"
+    full = gather_rows(out.cpu() if host else out, n_obj, bounds, group=group)
+    full = None if full is None else full.cpu().numpy()
+    if not return_status:
+        return full
+    full_st = None
+    if status is not None:
+        full_st = gather_rows(status.cpu() if host else status, n_obj, bounds, group=group)
+        full_st = None if full_st is None else full_st.cpu().numpy()
+    return (full, full_st) if rank == 0 else None
+
+
+def extract_multi_gpu(sets, csr, z=None, ngpu=2, backend=None, timeout_s=None):
+    """``extract_sharded`` for a caller that is ONE ordinary process (the entry-point scripts, ``extract_all(ngpu=N)``):
+    starts ``ngpu`` child ranks with ``torch.distributed.run`` -- new processes, so none of them has touched a GPU
+    before it selects its own -- hands them the batch through memory-mapped ``.npy`` files, and returns rank 0's
+    ``(matrix, status)``.  Backend ``nccl`` (RCCL) when the node has a GPU per rank, else ``gloo`` with the ranks
+    sharing the visible GPUs round-robin (``LCFE_DIST_BACKEND`` overrides)."""
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+
+    from . import _lib
+    from .engine import mask_of
+    from .packing import check_csr
+
+    mask = mask_of(sets)
+    n_obj, _ = check_csr(csr)
+    lib = _lib.load()
+    ndev = lib.lcfe_device_count()
+    if ndev < 1:
+        raise _lib.LcfeError("extract_multi_gpu: no HIP device visible (lcfe has no CPU fallback)")
+    if backend is None:
+        backend = os.environ.get("LCFE_DIST_BACKEND") or ("nccl" if ndev >= ngpu else "gloo")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="lcfe_dist_", dir=shm)
+    try:
+        for k in ("offsets", "t", "flux", "err", "band"):
+            np.save(os.path.join(tmp, f"{k}.npy"), np.ascontiguousarray(csr[k]))
+        if z is not None:
+            np.save(os.path.join(tmp, "z.npy"), np.ascontiguousarray(z, np.float64))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(ngpu)}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), worker, tmp, str(mask), backend]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0 or not os.path.exists(os.path.join(tmp, "out.npy")):
+            raise _lib.LcfeError(f"extract_multi_gpu: the {ngpu}-rank run failed (rc {r.returncode}):\n"
+                                 + (r.stdout + r.stderr)[-4000:])
+        out = np.load(os.path.join(tmp, "out.npy"))
+        st_path = os.path.join(tmp, "status.npy")
+        status = np.load(st_path) if os.path.exists(st_path) else None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if out.shape[0] != n_obj:
+        raise _lib.LcfeError(f"extract_multi_gpu: {out.shape[0]} rows came back for {n_obj} objects")
+    return out, status

@@ -1,58 +1,137 @@
-"""Shared DataFrame plumbing of the extractors: pack -> C-ABI -> frame."""
+"""Shared DataFrame plumbing of the extractors: pack -> C-ABI -> frames.
+
+``extract_all`` is the engine-speed form of the drop-in boundary: ONE ``pack_lightcurves`` of the long frame and ONE
+``lcfe_extract(mask)`` for every requested feature set (the sets then run side by side on the engine's streams and
+the CSR batch crosses PCIe once), cut into the per-extractor frames the reference's functions return.  The
+``extract_*_features`` mirrors are one-set calls of it.  ``ngpu > 1`` (or ``LCFE_NGPU``) shards the batch over the
+GPUs of the node through ``dist.extract_multi_gpu`` (one child process per GPU, started before any GPU call of theirs).
+"""
+import os
+import warnings
+
 import numpy as np
 
-from ..columns import COLUMNS
-from ..engine import extract_csr
+from ..columns import COLUMNS, SET_NAMES, STAT_INT_COLUMNS
+from ..engine import extract_csr, mask_of, sets_of
 from ..packing import pack_lightcurves
 
+# frame conventions of the reference's extractors: where ``object_id`` sits and which columns are int64
+#   statistical.py:214-226 (id first, *_n_obs / peak_band int64); train_v55_powerlaw.py:196-202 (dict with the id first);
+#   every other extractor appends the id last (colors.py:377, bazin_fitting.py:283, multiband_gp.py:381, ...)
+ID_FIRST = {"stat", "powerlaw"}
+INT_COLUMNS = {"stat": STAT_INT_COLUMNS}
+# sets that read the redshift column of the metadata (physics_based.py:481, research_features.py:552-559)
+NEEDS_Z = {"physics", "research"}
 
-# longest light curve (rows) a feature set's largest kernel tier takes; longer objects (bands, for the per-band GP)
-# come back as NaN with status -100 where the reference would compute values (INTEGRATION.md "Limits")
-SET_LIMITS = {"bazin": 2048, "powerlaw": 1024, "gp2d": 767, "gp1d": 767, "research": 1024}
+
+def _limit_message(set_name, csr, rows, lib):
+    """What the objects `rows` of a set ran into (status -100): the message names the limit that was hit, so that a
+    limit-NaN can be told from a failed fit."""
+    n = np.diff(csr["offsets"])[rows]
+    max_rows = int(lib.lcfe_max_points())
+    if set_name in ("bazin", "powerlaw"):
+        over_rows = int((n > max_rows).sum())
+        parts = []
+        if over_rows:
+            parts.append(f"{over_rows} with more than {max_rows} rows")
+        if len(rows) - over_rows:
+            what = "a band of more than 256 rows" if set_name == "bazin" else "more than 256 post-peak rows in a band"
+            parts.append(f"{len(rows) - over_rows} with {what} inside a light curve of more than 1024 rows")
+        return ", ".join(parts)
+    if set_name == "gp2d":
+        return f"more than {int(lib.lcfe_gp2d_max_points())} valid points"
+    if set_name == "gp1d":
+        return "a band of more than 767 valid points or more than 767 rows"
+    if set_name == "research":
+        return "an r band spanning more than the Mexican-hat grid of the kernel (status -100)"
+    return f"more than {max_rows} rows"
 
 
-def _extract_and_warn(set_name, csr, z, kept):
-    """Run one set and warn -- with the count and the first ids -- about objects beyond its tier limit: their NaN
-    rows are otherwise indistinguishable from "the fit failed" NaNs."""
-    import warnings
-
-    from .. import _lib
-    lib = _lib.load()
+def _warn_limits(names, csr, kept, status, lib):
+    """RuntimeWarning -- with the count, the cause and the first ids -- for the objects a set returned NaN for because
+    they are beyond a kernel limit: such rows are otherwise indistinguishable from "the fit failed" NaNs."""
     n = np.diff(csr["offsets"])
-    if lib.lcfe_nstatus(1 << _lib_set_index(set_name)):
-        out, status = extract_csr(set_name, csr, z=z, return_status=True)
-        over = np.flatnonzero((status == -100).any(axis=1))
+    st0 = 0
+    for name in names:
+        nst = int(lib.lcfe_nstatus(1 << SET_NAMES.index(name)))
+        if nst:
+            over = np.flatnonzero((status[:, st0:st0 + nst] == -100).any(axis=1))
+            st0 += nst
+        else:
+            over = np.flatnonzero(n > lib.lcfe_max_points())
+        if over.size:
+            warnings.warn(f"lcfe[{name}]: {over.size} object(s) beyond a kernel limit got NaN (status -100): "
+                          f"{_limit_message(name, csr, over, lib)}; e.g. {[kept[i] for i in over[:5]]}",
+                          RuntimeWarning, stacklevel=4)
+
+
+def frame_of(set_name, block, kept):
+    """The DataFrame an extractor of the reference returns for `set_name` from its block of the feature matrix."""
+    import pandas as pd
+
+    df = pd.DataFrame(block, columns=COLUMNS[set_name])
+    for c in INT_COLUMNS.get(set_name, ()):
+        df[c] = df[c].astype(np.int64)
+    if set_name in ID_FIRST:
+        df.insert(0, "object_id", kept)
     else:
-        out = extract_csr(set_name, csr, z=z)
-        over = np.flatnonzero(n > lib.lcfe_max_points())
-    if over.size:
-        limit = SET_LIMITS.get(set_name, int(lib.lcfe_max_points()))
-        what = "a band longer than 767 valid points or more than 767 rows" if set_name == "gp1d" else f"more than {limit} rows"
-        warnings.warn(f"lcfe[{set_name}]: {over.size} object(s) with {what} are beyond the largest kernel tier and "
-                      f"got NaN (status -100), e.g. {[kept[i] for i in over[:5]]}", RuntimeWarning, stacklevel=3)
-    return out
+        df["object_id"] = kept
+    return df
 
 
-def _lib_set_index(set_name):
-    from ..columns import SET_NAMES
-    return SET_NAMES.index(set_name)
+def redshifts(metadata, kept):
+    """z per kept object: ``z_lookup.get(obj_id, nan)`` (physics_based.py:481,496)."""
+    zmap = dict(zip(metadata["object_id"], metadata["Z"]))
+    return np.array([zmap.get(i, np.nan) for i in kept], dtype=np.float64)
+
+
+def default_ngpu():
+    try:
+        return max(1, int(os.environ.get("LCFE_NGPU", "1")))
+    except ValueError:
+        return 1
+
+
+def extract_all(lightcurves=None, metadata=None, object_ids=None, sets=None, csr=None, ngpu=None, return_matrix=False):
+    """Every requested feature set from ONE pack and ONE engine call.
+
+    ``lightcurves``: the long frame (``object_id, Time (MJD), Flux, Flux_err, Filter``), or pass ``csr=(csr, ids)``
+    as ``utils.data_loader.load_lightcurves_csr`` / ``packing.pack_lightcurves`` return it (``object_ids`` then selects
+    and orders objects of that batch).  ``sets``: names (default: all ten).  Returns ``{set name: DataFrame}`` with the
+    reference's conventions per extractor; with ``return_matrix`` also the raw ``(matrix, status, kept_ids)``."""
+    from .. import _lib
+    from ..packing import select_objects
+
+    lib = _lib.load()
+    names = sets_of(mask_of(list(SET_NAMES) if sets is None else sets))         # canonical (column) order
+    mask = mask_of(names)
+    if csr is not None:
+        batch, ids = csr
+        batch, kept = (batch, list(ids)) if object_ids is None else select_objects(batch, ids, object_ids)
+    else:
+        batch, kept = pack_lightcurves(lightcurves, object_ids)
+    z = None
+    if metadata is not None and (NEEDS_Z & set(names)):
+        z = redshifts(metadata, kept)
+    ngpu = default_ngpu() if ngpu is None else int(ngpu)
+    if ngpu > 1:
+        from ..dist import extract_multi_gpu
+        out, status = extract_multi_gpu(mask, batch, z, ngpu)
+    else:
+        res = extract_csr(mask, batch, z=z, return_status=True)
+        out, status = res
+    _warn_limits(names, batch, kept, status, lib)
+    frames, col0 = {}, 0
+    for name in names:
+        ncol = len(COLUMNS[name])
+        frames[name] = frame_of(name, out[:, col0:col0 + ncol], kept)
+        col0 += ncol
+    if return_matrix:
+        return frames, (out, status, kept)
+    return frames
 
 
 def run_extractor(set_name, lightcurves, object_ids=None, metadata=None, id_last=True, int_columns=()):
-    import pandas as pd
-
-    csr, kept = pack_lightcurves(lightcurves, object_ids)
-    z = None
-    if metadata is not None:
-        # physics_based.py:481,496: z_lookup.get(obj_id, nan)
-        zmap = dict(zip(metadata["object_id"], metadata["Z"]))
-        z = np.array([zmap.get(i, np.nan) for i in kept], dtype=np.float64)
-    out = _extract_and_warn(set_name, csr, z, kept)
-    df = pd.DataFrame(out, columns=COLUMNS[set_name])
-    for c in int_columns:
-        df[c] = df[c].astype(np.int64)
-    if id_last:
-        df["object_id"] = kept
-    else:
-        df.insert(0, "object_id", kept)
-    return df
+    """One extractor of the reference = a one-set call of ``extract_all`` (``id_last`` / ``int_columns`` are implied by
+    the set and kept in the signature for the mirrors that spell them out)."""
+    return extract_all(lightcurves, metadata=metadata, object_ids=object_ids, sets=[set_name])[set_name]

@@ -69,6 +69,33 @@ def pack_lightcurves(lightcurves, object_ids=None):
     return {"offsets": offsets, "t": t, "flux": f, "err": e, "band": b}, list(kept_ids)
 
 
+def select_objects(csr, ids, object_ids):
+    """Objects ``object_ids`` of an existing CSR batch (``ids[k]`` names object k), in the order of ``object_ids`` --
+    what ``pack_lightcurves(frame, object_ids)`` returns for the frame the batch was packed from: ids without rows
+    (or unknown) are dropped, a repeated id repeats its object.  Returns ``(csr, kept_ids)``; no copy when the
+    selection is the whole batch in its own order."""
+    ids = list(ids)
+    object_ids = list(object_ids)
+    if object_ids == ids:
+        return csr, ids
+    pos = {}
+    for k, i in enumerate(ids):
+        pos.setdefault(i, k)                             # first occurrence, as Categorical codes do
+    off = np.asarray(csr["offsets"], np.int64)
+    sel = [pos[i] for i in object_ids if i in pos and off[pos[i] + 1] > off[pos[i]]]
+    kept = [ids[k] for k in sel]
+    sel = np.asarray(sel, np.int64)
+    n = off[sel + 1] - off[sel] if len(sel) else np.zeros(0, np.int64)
+    offsets = np.zeros(len(sel) + 1, np.int64)
+    np.cumsum(n, out=offsets[1:])
+    # row gather: for object j rows off[sel[j]] .. off[sel[j] + 1]
+    gather = (np.repeat(off[sel] - offsets[:-1], n) + np.arange(offsets[-1])) if len(sel) else np.zeros(0, np.int64)
+    out = {"offsets": offsets}
+    for k in ("t", "flux", "err", "band"):
+        out[k] = np.ascontiguousarray(np.asarray(csr[k])[gather])
+    return out, kept
+
+
 def check_csr(csr):
     """Host-side shape checks done before any kernel launch (a malformed CSR must never reach
     the device: an out-of-bounds read can reset the GPU)."""

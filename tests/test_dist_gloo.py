@@ -50,14 +50,44 @@ def test_shards_of_config4_are_cost_balanced():
     assert np.array_equal(shard_bounds(offsets, 8), b)
 
 
+def test_int_mask_is_accepted_like_a_set_list():
+    """`extract_sharded` forwards the caller's `sets` to the cost model: an int mask (what mask_of / DeviceBatch.run
+    accept) must shard exactly like the list of names it stands for."""
+    from mallorn_astrophysics_amd.engine import mask_of
+    lc = synth.make_lightcurves(300, seed=5)
+    for names in (["stat"], ["stat", "gp2d"], ["bazin", "gp1d"], ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d"]):
+        m = mask_of(names)
+        assert np.array_equal(shard_bounds(lc["offsets"], 4, m), shard_bounds(lc["offsets"], 4, names)), names
+        assert np.array_equal(shard_bounds(lc["offsets"], 4, np.int64(m)), shard_bounds(lc["offsets"], 4, names))
+        sub_m = shard_csr(lc, 2, 4, lc["z"], m)
+        sub_n = shard_csr(lc, 2, 4, lc["z"], names)
+        assert sub_m[2] == sub_n[2] and np.array_equal(sub_m[0]["flux"], sub_n[0]["flux"])
+
+
+def test_shards_of_the_config5_survey_are_cost_balanced():
+    """Config 5 as bench.py --gpus 8 draws it: ONE survey of 8 x 125,000 objects (block b = seed 1000000 + b) cut into
+    8 cost-balanced contiguous shards.  The predicted cost of the heaviest shard stays within 5 % of the mean, and a
+    shard differs from its block by a fraction of a percent (so a rank generates at most two blocks)."""
+    from mallorn_astrophysics_amd.dist import object_costs
+    n_all = np.concatenate([synth.lengths(125000, seed=1000000 + b) for b in range(8)])
+    offsets = np.concatenate([[0], np.cumsum(n_all)]).astype(np.int64)
+    sets = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d"]
+    b = shard_bounds(offsets, 8, sets)
+    cost = object_costs(offsets, sets)
+    per = np.array([cost[b[r]:b[r + 1]].sum() for r in range(8)])
+    assert per.max() / per.mean() <= 1.05, per / per.mean()
+    assert np.abs(np.diff(b) - 125000).max() <= 2500, np.diff(b)
+
+
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     lc = synth.make_lightcurves(37, seed=21)
-    bounds = shard_bounds(lc["offsets"], world, ["stat"])
-    sub, sub_z, (lo, hi) = shard_csr(lc, rank, world, lc["z"], ["stat"])
+    sets = ["stat"] if world == 2 else 1          # an int mask is as good as the names (world 3)
+    bounds = shard_bounds(lc["offsets"], world, sets)
+    sub, sub_z, (lo, hi) = shard_csr(lc, rank, world, lc["z"], sets)
     local = torch.from_numpy(oracle.extract("stat", sub, sub_z))
     assert local.shape[0] == hi - lo
     full = gather_rows(local, 37, bounds)

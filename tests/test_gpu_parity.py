@@ -540,3 +540,55 @@ def test_all_ten_sets_in_one_call_equal_the_single_set_calls(golden_inputs):
         col += one.shape[1]
         assert np.array_equal(np.nan_to_num(blk, nan=-7.0), np.nan_to_num(one, nan=-7.0)), name
     assert col == both.shape[1] == sum(len(COLUMNS[n]) for n in names)
+
+
+def test_sets_do_not_depend_on_the_statistics_set_being_in_the_mask():
+    """The statistics set routes its light curves through lists of its own: the tier lists the other sets read are never
+    appended to (round-2 advice: a 128-row-tier light curve the lanes kernels could not take used to be appended to the
+    256-row tier's list, so every other set processed it twice whenever `stat` was in the mask, and the per-tier fit
+    lists -- sized for one pass -- could overflow).  Worst case for the fit lists: every object has six fit-able bands
+    of 5..32 rows (all fits in tier 0), a few light curves of up to 128 rows carry one 40-row band (not lane-eligible
+    at 8 lanes), one is longer than 128 rows.  All sets in ONE call must equal the single-set calls bit for bit, and
+    the streaming sets the oracle."""
+    rng = np.random.default_rng(2026)
+    objs = []
+
+    def add(counts):
+        n = int(sum(counts))
+        t = np.sort(59000 + rng.uniform(0, 600, n))
+        b = rng.permutation(np.repeat(np.arange(6), counts)).astype(np.int64)
+        f = 25 * np.exp(-0.5 * ((t - 59250) / 45) ** 2) * (1 + 0.2 * b) + rng.normal(0, 1.0, n)
+        objs.append((t, f, rng.uniform(0.4, 1.5, n), b))
+
+    for _ in range(300):
+        add(rng.integers(5, 22, 6))                       # six fit-able bands, <= 128 rows in all
+    for _ in range(6):
+        c = rng.integers(5, 16, 6)
+        c[rng.integers(0, 6)] = 40                        # one 40-row band inside a <= 128-row light curve
+        add(c)
+    add([30, 30, 30, 30, 30, 30])                         # 180 rows: the 256-row tier exists in this batch
+    order = rng.permutation(len(objs))
+    lc = synth.from_objects([objs[i] for i in order])
+    assert np.diff(lc["offsets"]).max() > 128
+    names = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "research"]
+    got, status = extract_csr(names, lc, z=lc["z"], return_status=True)
+    key = lambda m: np.nan_to_num(m, nan=-7.25e300)
+    col0 = st0 = 0
+    for name in names:
+        one = extract_csr(name, lc, z=lc["z"], return_status=True)
+        one, st = one if isinstance(one, tuple) else (one, None)
+        ncol = one.shape[1]
+        assert np.array_equal(key(got[:, col0:col0 + ncol]), key(one)), f"{name}: depends on the other sets of the mask"
+        if st is not None and st.shape[1]:
+            assert np.array_equal(status[:, st0:st0 + st.shape[1]], st), name
+            st0 += st.shape[1]
+        if name in TOL:
+            ref = oracle.extract(name, lc, lc["z"])
+            bad = parity.compare(one, ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
+            assert not bad, "\n".join(bad)
+        col0 += ncol
+    # every band of 5+ rows was fitted exactly once: no Bazin column group is left unwritten
+    baz = got[:, 123:123 + 48].reshape(len(order), 6, 8)
+    stb, nfev = status[:, 0:12:2], status[:, 1:12:2]
+    assert (nfev > 0).all(), "a Bazin band fit was queued but never run"
+    assert np.isfinite(baz[stb > 0]).all()
