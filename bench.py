@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak of MI355X: v_mfma_f64_16x16x4 = 2048 flop / 64 cycles / SIMD x 1024 SIMDs x 2.4 GHz
+                               # (= the fp64 vector rate; the guide's table has no fp64 row)
 NCOLS = {"stat": 123, "bazin": 52, "powerlaw": 27, "tde": 25, "color": 83, "shape": 65, "physics": 32, "gp2d": 27,
          "gp1d": 21, "research": 40}
 
@@ -224,13 +226,16 @@ def main():
     pending = [None, None]
     counter = [0]
 
+    nst = int(lib.lcfe_nstatus(mask))
+    status = torch.zeros((n_local, nst), dtype=torch.int32, device=batch.device) if nst else None
+
     def step(prof=False):
         b = counter[0] & 1
         counter[0] += 1
         if pending[b] is not None:
             pending[b].wait()                 # the buffer's previous gather has to be done before it is rewritten
             pending[b] = None
-        r = batch.run(mask, out=outs[b][:n_local], prof=prof)
+        r = batch.run(mask, out=outs[b][:n_local], status=status, prof=prof)
         if use_dist:
             pending[b] = dist.gather(outs[b], gathered, dst=0, async_op=True)
         return r[2] if prof else None
@@ -255,19 +260,30 @@ def main():
     note("warmup done")
     kernel_ms = np.zeros(len(SET_NAMES))
     t0 = time.perf_counter()
+    busy = 0.0                                # this rank's own kernel time: a step with prof drains the rank's stream
     for _ in range(a.steps):
+        ts = time.perf_counter()
         p = step(prof=True)
+        busy += time.perf_counter() - ts
         kernel_ms += np.array(p["kernel_ms"])
         note(f"step {_ + 1}/{a.steps}")
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=batch.device)
+    # per-rank diagnostics of a multi-GPU run: own step time (without waiting for the others) and shard size
+    from mallorn_astrophysics_amd.dist import object_costs
+    mine = torch.tensor([busy / a.steps * 1e3, float(n_local), float(lc["offsets"][-1]),
+                         float(object_costs(lc["offsets"], sets).sum()) * 1e3], dtype=torch.float64, device=batch.device)
+    per_rank = [mine]
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     dt = float(tmax.item())
     if rank != 0:
         dist.destroy_process_group()
         return
+    per_rank = np.array([x.cpu().numpy() for x in per_rank])
 
     n_pts = int(lc["offsets"][-1])
     kernel_ms /= a.steps
@@ -281,9 +297,34 @@ def main():
     # HBM traffic of the roofline kernel from PMC counters (collected offline in separate rocprofv3
     # --pmc passes on this exact workload; bench.py cannot run under the counters itself)
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r02_stat_traffic.json")
-    if rk == "stat" and world == 1 and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
-        traffic = json.load(open(tj)).get("hbm_bytes_per_pass")
+    traffic_src = None
+    for rr in ("r03", "r02"):
+        tj = os.path.join(ROOT, "profiles", f"{rr}_stat_traffic.json")
+        if rk == "stat" and world == 1 and a.objects == 125000 and a.seed == 1000000 and os.path.exists(tj):
+            traffic = json.load(open(tj)).get("hbm_bytes_per_pass")
+            traffic_src = f"profiles/{rr}_stat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload)"
+            break
+    # the kernel that decides `value`: the 2-D GP.  Flops from the status words of the last pass: every L-BFGS-B
+    # evaluation sweeps the N x N Gram matrix (N^3 flops on the fp64 MFMA: lower-triangle tiles, N/16 pivot steps) and
+    # builds the Gram matrix and the gradient (30 N^2); the prediction pass at the optimum adds one sweep.
+    extra = {}
+    if "gp2d" in sets and status is not None:
+        st0 = 0
+        for sname in sets:
+            if sname == "gp2d":
+                break
+            st0 += int(lib.lcfe_nstatus(mask_of([sname])))
+        stg = status[:, st0:st0 + 4].cpu().numpy().astype(np.float64)
+        n_eval, n_valid = stg[:, 2], stg[:, 3]
+        fitted = n_eval > 0
+        flops = float(((n_eval + 1) * n_valid ** 3 + n_eval * 30.0 * n_valid ** 2)[fitted].sum())
+        gp_ms = per_set["gp2d"]
+        extra["gp2d"] = {"kernel": "gp_kernel<NP> tiers (L-BFGS-B over a blocked symmetric sweep on v_mfma_f64_16x16x4)",
+                         "bound": "mfma", "flops": flops, "evaluations": float(n_eval.sum()), "objects_fitted": int(fitted.sum()),
+                         "ms": gp_ms, "achieved": flops / (gp_ms * 1e-3) / 1e12 if gp_ms > 0 else 0.0, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (gp_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if gp_ms > 0 else 0.0,
+                         "note": "flops = sum over objects of (n_eval + 1) N^3 + n_eval 30 N^2 (N = valid points, n_eval from the "
+                                 "status words); ms = the set's HIP-event time (it shares the chip with the fit kernels unless LCFE_SERIAL=1)"}
     res = {
         "metric": "light curves/sec", "value": a.objects * world * a.steps / dt, "unit": "light curves/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -297,9 +338,15 @@ def main():
         "kernel_ms_note": ("per-set HIP-event times on one stream (LCFE_SERIAL=1)" if os.environ.get("LCFE_SERIAL") == "1" else
                            "statistics (+ binning) runs alone; the other sets run concurrently on forked streams, "
                            "so their event times overlap and do not add up to ms_per_step"),
-        "roofline": {"kernel": "statistics set: bin_kernel, stat_plan_kernel<16|32>, stat_lanes_all_kernel, stat_lean_kernel<256|512>, fallback launch" if rk == "stat" else f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"kernel": "statistics set: bin_kernel, stat_plan_kernel, stat_lanes_all_kernel, stat_lean_kernel<256|512>, fallback launch" if rk == "stat" else f"set_kernel<{rk}>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": per_set[rk]},
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": per_set[rk]},
+        "roofline_extra": extra,
+        "ranks": {"step_ms_min_mean_max": [float(per_rank[:, 0].min()), float(per_rank[:, 0].mean()), float(per_rank[:, 0].max())],
+                  "per_rank": [{"rank": r, "step_ms": float(per_rank[r, 0]), "objects": int(per_rank[r, 1]), "points": int(per_rank[r, 2]),
+                                "predicted_ms": float(per_rank[r, 3])} for r in range(len(per_rank))],
+                  "note": "step_ms = a rank's own kernel time per step (host clock around the engine call, which drains the "
+                          "rank's stream); predicted_ms = dist.object_costs summed over the rank's shard"},
     }
     if not a.no_cpu_baseline:
         note("timing the CPU oracle on the host cores")

@@ -117,6 +117,8 @@ void lcfe_release_buffers(void);
 
 /* largest number of points per object any kernel tier accepts */
 int64_t lcfe_max_points(void);
+/* largest number of VALID points (known band, finite flux and error, error > 0) per object the 2-D GP accepts */
+int64_t lcfe_gp2d_max_points(void);
 /* mask of the feature sets this build of the library implements */
 int lcfe_implemented_mask(void);
 

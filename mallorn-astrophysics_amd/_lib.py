@@ -81,6 +81,7 @@ def load():
     lib.lcfe_colname.restype = ctypes.c_char_p
     lib.lcfe_colname.argtypes = [ctypes.c_int, ctypes.c_int64]
     lib.lcfe_max_points.restype = ctypes.c_int64
+    lib.lcfe_gp2d_max_points.restype = ctypes.c_int64
     lib.lcfe_implemented_mask.restype = ctypes.c_int
     lib.lcfe_workspace_bytes.restype = ctypes.c_size_t
     lib.lcfe_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]

@@ -1513,6 +1513,8 @@ const char* lcfe_last_error(void) { return g_err.c_str(); }
 
 int64_t lcfe_max_points(void) { return kMaxPoints; }
 
+int64_t lcfe_gp2d_max_points(void) { return kGpGlobalNP - 1; }
+
 int lcfe_implemented_mask(void) {
     int m = 0;
     for (int s = 0; s < NUM_SETS; ++s)

@@ -78,12 +78,15 @@ def select_objects(csr, ids, object_ids):
     object_ids = list(object_ids)
     if object_ids == ids:
         return csr, ids
+    # ids are matched by their text: the C++ reader returns the id column as strings, a metadata frame read by pandas
+    # may hold the same ids as integers; the kept ids are the caller's objects
     pos = {}
     for k, i in enumerate(ids):
-        pos.setdefault(i, k)                             # first occurrence, as Categorical codes do
+        pos.setdefault(str(i), k)                        # first occurrence, as Categorical codes do
     off = np.asarray(csr["offsets"], np.int64)
-    sel = [pos[i] for i in object_ids if i in pos and off[pos[i] + 1] > off[pos[i]]]
-    kept = [ids[k] for k in sel]
+    hit = [(pos[str(i)], i) for i in object_ids if str(i) in pos and off[pos[str(i)] + 1] > off[pos[str(i)]]]
+    sel = [k for k, _ in hit]
+    kept = [i for _, i in hit]
     sel = np.asarray(sel, np.int64)
     n = off[sel + 1] - off[sel] if len(sel) else np.zeros(0, np.int64)
     offsets = np.zeros(len(sel) + 1, np.int64)

@@ -46,6 +46,9 @@ def fit_blocks(name):
         return [(j, j + 1) for j in range(27)]
     if name == "gp2d":
         return [(0, 27)]
+    if name == "gp1d":
+        # four columns per band fit (g, r, i, z), then the five cross-band columns derived from all of them
+        return [(4 * k, 4 * k + 4) for k in range(4)] + [(16, 21)]
     raise KeyError(name)
 
 

@@ -67,3 +67,36 @@ def test_bad_csr_rejected_on_host():
     bad = dict(lc); bad["t"] = lc["t"][:-1]
     with pytest.raises(ValueError):
         check_csr(bad)
+
+
+def test_multi_gpu_launcher_fails_loudly_without_gpu():
+    """`extract_all(ngpu=2)` / `dist.extract_multi_gpu` on a box without a GPU: an error, not a CPU result."""
+    lib = _lib.load()
+    if lib.lcfe_device_count() > 0:
+        pytest.skip("GPU present")
+    from mallorn_astrophysics_amd import synth
+    from mallorn_astrophysics_amd.dist import extract_multi_gpu
+    lc = synth.make_lightcurves(3, seed=1)
+    with pytest.raises(_lib.LcfeError):
+        extract_multi_gpu(["stat"], lc, None, ngpu=2)
+
+
+def test_select_objects_equals_pack_lightcurves():
+    """`packing.select_objects` on a packed batch == `pack_lightcurves(frame, object_ids)`: order of the request,
+    unknown and row-less ids dropped, repeated ids repeated; ids are matched by their text (the C++ reader returns
+    strings where pandas may have parsed integers)."""
+    from mallorn_astrophysics_amd import synth
+    from mallorn_astrophysics_amd.packing import pack_lightcurves, select_objects
+    lc = synth.make_lightcurves(40, seed=3)
+    ids = [1000 + k for k in range(40)]                      # integer ids, as pandas parses a numeric id column
+    df, _ = synth.to_dataframe(lc, ids)
+    csr0, k0 = pack_lightcurves(df)
+    rng = np.random.default_rng(0)
+    want = [ids[i] for i in rng.permutation(40)[:25]] + [5, ids[3], ids[3]]
+    a, ka = pack_lightcurves(df, want)
+    b, kb = select_objects(csr0, [str(i) for i in k0], want)        # batch ids as text
+    assert ka == kb
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    same, ks = select_objects(csr0, k0, list(k0))
+    assert same is csr0 and ks == list(k0)
