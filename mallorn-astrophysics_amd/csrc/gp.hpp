@@ -78,9 +78,14 @@ template <int NP, int LDV> struct GpSmallArrays<NP, LDV, true> {
     LCFE_FN double* rbuf(double (*V)[LDV]) { return &V[0][0]; }
 };
 
-template <int NP, int NW = 4, bool FUSE = false>
+// staging tile of the pivot look-ahead (workgroups of four or more wavefronts; a single wavefront has nobody to overlap with)
+template <bool ON> struct GpStageTile { double stage[1]; };
+template <> struct GpStageTile<true> { double stage[GP_B * GP_B]; };
+
+template <int NP, int NW = 4, bool FUSE = false, bool LOOKAHEAD = true>
 struct GpLds {
     static constexpr bool kFuse = FUSE;
+    static constexpr bool kLookAhead = LOOKAHEAD && NW >= 4;
     double t[NP], y[NP], e2[NP];              // valid points: time (from first valid), flux/scale, (err/scale)^2
     double alpha[NP];                         // K^-1 r
     GpSmallArrays<NP, gp_panel_ld(NP), FUSE> sm;
@@ -92,6 +97,8 @@ struct GpLds {
     double slot[2];
     double out[GP_NCOL + 1];
     int pivot_bad;                            // wave 0 reports a non-positive pivot
+    int row_ticket;                           // tile rows of an update phase are handed out longest first
+    GpStageTile<(LOOKAHEAD && NW >= 4)> la;                // wavefront 0: layout changes of the pivot look-ahead (one tile)
 #ifdef LCFE_GP_PROF
     unsigned long long prof[12];
 #endif
@@ -274,6 +281,66 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
             return wd;
         };
 
+        // ---- pivot look-ahead.  The Gauss-Jordan inverse of a 16 x 16 pivot block is a chain of 16 dependent
+        // reciprocals on ONE wavefront (19-36 % of an evaluation when every other wavefront waits for it).  The pivot block
+        // of the NEXT step is final as soon as the current step has been applied to that one tile, so wavefront 0 applies
+        // it to that tile first -- the same MFMAs in the same order as the update loop, which then skips the tile -- and
+        // inverts the block while the other wavefronts update the rest of the matrix; the inverse waits in its registers
+        // for the next step.  Tile rows are handed out by a ticket (longest first), so wavefront 0 simply takes fewer rows.
+        // Operation for operation the arithmetic of the step-by-step schedule: bit-identical results.
+        constexpr bool kLookAhead = LDS::kLookAhead;
+        double pn1[4] = {0, 0, 0, 0}, pn2[4] = {0, 0, 0, 0};      // wavefront 0: -(-D^-1) of the next pivot block(s), Gauss-Jordan layout
+        bool have1 = false, have2 = false;                         // (uniform) the next step's inverse(s) are already known
+        auto* row_ticket = (__attribute__((address_space(3))) int*)(&S.row_ticket);
+        auto grab_row = [&]() -> int {
+            int r = 0;
+            if (l == 0) r = __hip_atomic_fetch_add(row_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return nt - 1 - __builtin_amdgcn_readfirstlane(r);
+        };
+        // tile in D layout -> Gauss-Jordan layout through the staging tile (lower half mirrored, identity padding beyond
+        // bs: exactly what gather + invert read), inverse -> pout (wavefront 0 only)
+        auto stage_invert = [&](const gp_v4f64& c, int bs, double (&pout)[4]) {
+            const int a = l >> 2, cq = l & 3;
+            W::wave_sync();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S.la.stage[((lr + 4 * v) << 4) + lc] = c[v];
+            W::wave_sync();
+            double p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bq = 4 * cq + r;
+                const double x = (a >= bq) ? S.la.stage[(a << 4) + bq] : S.la.stage[(bq << 4) + a];
+                p[r] = (a < bs && bq < bs) ? x : ((a == bq) ? 1.0 : 0.0);
+            }
+            bool bad = false;
+            gp_inv16_pivots<0>(p, a, cq, bad, prod, ld);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pout[r] = -p[r];
+            if (bad && l == 0) S.pivot_bad = 1;
+        };
+        auto write_P = [&](double (*Pp)[GP_B], const double (&pin)[4]) {
+            const int a = l >> 2, cq = l & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pp[a][4 * cq + r] = pin[r];
+        };
+        // C_ij -= W_i V_j' with W_i in A layout (negated) against panel Vp
+        auto rank16 = [&](gp_v4f64 c, const gp_v4f64& wt, double (*Vp)[LDV], int j) {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-wt[kc], Vp[4 * kc + lr][(j << 4) + lc], c, 0, 0, 0);
+            return c;
+        };
+        auto load_tile = [&](KP T) {
+            gp_v4f64 c;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) c[v] = T[((lr + 4 * v) << 4) + lc];
+            return c;
+        };
+        auto store_tile = [&](KP T, const gp_v4f64& c) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+        };
+
+        if (W::lane() == 0) S.pivot_bad = 0;
         int kt = 0, k0 = 0;
         while (k0 < n) {
             if constexpr (LDS::kFuse) {
@@ -287,11 +354,12 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                     auto& P2 = S.fz.P2;
                     GP_T0();
                     gather(S.V, a, GP_B);
-                    if (W::lane() == 0) S.pivot_bad = 0;
+                    if (w == 0 && have1) write_P(S.P, pn1);
+                    if (w == 0 && have2) write_P(P2, pn2);
+                    if (W::lane() == 0) S.row_ticket = 0;
                     W::sync();
                     GP_T(0);
-                    invert(S.V, S.P, k0, GP_B);
-                    W::sync();
+                    if (!have1) { invert(S.V, S.P, k0, GP_B); W::sync(); }
                     if (S.pivot_bad != 0) return false;
                     GP_T(1);
                     double dA1[4];
@@ -334,17 +402,57 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                     W::sync();
                     gather(V2, b, GP_B);
                     W::sync();
-                    invert(V2, P2, k0 + GP_B, GP_B);
-                    W::sync();
+                    if (!have2) { invert(V2, P2, k0 + GP_B, GP_B); W::sync(); }
                     if (S.pivot_bad != 0) return false;
                     GP_T(2);
                     double dA2[4];
 #pragma unroll
                     for (int kc = 0; kc < 4; ++kc) dA2[kc] = P2[lc][4 * kc + lr];
+                    // ---- look-ahead (wavefront 0): the pivot blocks of the next pass, a2 = b + 1 and -- when that pass takes two
+                    // tiles again -- b2 = b + 2.  Tiles (a2, a2), (b2, a2) and (b2, b2) get steps a and b here and are skipped below.
+                    const int rest = n - (k0 + 2 * GP_B);              // pivots left after this pass
+                    const bool la1 = kLookAhead && rest > 0, la2 = kLookAhead && rest >= 2 * GP_B;
+                    const int a2 = b + 1, b2 = b + 2;
+                    if (la1 && w == 0) {
+                        const gp_v4f64 w1a = w_alayout(dA1, S.V, a2), w2a = w_alayout(dA2, V2, a2);
+                        KP Taa = A + tile_base(a2, a2);
+                        gp_v4f64 c = rank16(rank16(load_tile(Taa), w1a, S.V, a2), w2a, V2, a2);
+                        store_tile(Taa, c);
+                        stage_invert(c, (rest < GP_B) ? rest : GP_B, pn1);
+                        if (la2) {
+                            // -D1'^-1 in A-operand layout (through the staging tile)
+                            W::wave_sync();
+                            write_P(reinterpret_cast<double (*)[GP_B]>(S.la.stage), pn1);
+                            W::wave_sync();
+                            double dAn[4];
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc) dAn[kc] = S.la.stage[(lc << 4) + 4 * kc + lr];
+                            const gp_v4f64 w1b = w_alayout(dA1, S.V, b2), w2b = w_alayout(dA2, V2, b2);
+                            KP Tba = A + tile_base(b2, a2);
+                            const gp_v4f64 cba = rank16(rank16(load_tile(Tba), w1b, S.V, a2), w2b, V2, a2);
+                            store_tile(Tba, cba);
+                            // the next pass's first panel at row b2: Vn[p][q] = A(16 b2 + q, 16 a2 + p)
+                            W::wave_sync();
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) S.la.stage[(lc << 4) + lr + 4 * v] = cba[v];
+                            W::wave_sync();
+                            double vb[4];
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc) vb[kc] = S.la.stage[((4 * kc + lr) << 4) + lc];
+                            gp_v4f64 wtn = {0, 0, 0, 0};                 // W'_b2 = (D1'^-1 Vn')' as in w_alayout
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc) wtn = __builtin_amdgcn_mfma_f64_16x16x4f64(dAn[kc], vb[kc], wtn, 0, 0, 0);
+                            KP Tbb = A + tile_base(b2, b2);
+                            gp_v4f64 cbb = rank16(rank16(load_tile(Tbb), w1b, S.V, b2), w2b, V2, b2);
+                            store_tile(Tbb, cbb);                        // steps a and b: what the next pass's step a2 starts from
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc) cbb = __builtin_amdgcn_mfma_f64_16x16x4f64(-wtn[kc], vb[kc], cbb, 0, 0, 0);
+                            stage_invert(cbb, GP_B, pn2);
+                        }
+                    }
                     // ---- both updates on every other tile, row by row
-                    for (int blk = 0;; ++blk) {
-                        const int pos = (blk & 1) ? NW - 1 - w : w;
-                        const int i = nt - 1 - (blk * NW + pos);
+                    for (;;) {
+                        const int i = grab_row();
                         if (i < 0) break;
                         if (i == b) {
                             // pivot row of step b: off-diagonal tiles come from the owners of the rows j < b (below)
@@ -386,19 +494,21 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                         constexpr int UNR = 2;      // tiles in flight (four were measured slower, also at 256 registers per lane)
                         for (int j0 = 0; j0 <= i; j0 += UNR) {
                             gp_v4f64 c[UNR];
-                            double b1[UNR][4], b2[UNR][4];
+                            double b1[UNR][4], b2v[UNR][4];
                             bool on[UNR], col_a[UNR];
 #pragma unroll
                             for (int u = 0; u < UNR; ++u) {
                                 const int j = j0 + u;
-                                on[u] = (j <= i) && (j != b);
+                                // (the look-ahead tiles are wavefront 0's)
+                                const bool ahead = (la1 && i == a2 && j == a2) || (la2 && i == b2 && (j == a2 || j == b2));
+                                on[u] = (j <= i) && (j != b) && !ahead;
                                 col_a[u] = (j == a);
                                 const int jj = (j <= i) ? j : i;
                                 KP T = A + tile_base(i, jj);
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) c[u][v] = T[((lr + 4 * v) << 4) + lc];
 #pragma unroll
-                                for (int kc = 0; kc < 4; ++kc) { b1[u][kc] = S.V[4 * kc + lr][(jj << 4) + lc]; b2[u][kc] = V2[4 * kc + lr][(jj << 4) + lc]; }
+                                for (int kc = 0; kc < 4; ++kc) { b1[u][kc] = S.V[4 * kc + lr][(jj << 4) + lc]; b2v[u][kc] = V2[4 * kc + lr][(jj << 4) + lc]; }
                             }
 #pragma unroll
                             for (int u = 0; u < UNR; ++u) {
@@ -412,7 +522,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
 #pragma unroll
                             for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
-                                for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(n2[kc], b2[u][kc], c[u], 0, 0, 0);
+                                for (int u = 0; u < UNR; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(n2[kc], b2v[u][kc], c[u], 0, 0, 0);
 #pragma unroll
                             for (int u = 0; u < UNR; ++u) {
                                 if (!on[u]) continue;
@@ -424,6 +534,8 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                     }
                     W::sync();
                     GP_T(8);
+                    have1 = la1;
+                    have2 = la2;
                     kt += 2;
                     k0 += 2 * GP_B;
                     continue;
@@ -432,11 +544,11 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
             const int bs = (n - k0 < GP_B) ? n - k0 : GP_B;
             GP_T0();
             gather(S.V, kt, bs);
-            if (W::lane() == 0) S.pivot_bad = 0;
+            if (w == 0 && have1) write_P(S.P, pn1);
+            if (W::lane() == 0) S.row_ticket = 0;
             W::sync();
             GP_T(0);
-            invert(S.V, S.P, k0, bs);
-            W::sync();
+            if (!have1) { invert(S.V, S.P, k0, bs); W::sync(); }
             if (S.pivot_bad != 0) return false;
             GP_T(1);
             // (3) own rows: W_i, pivot column / row tiles, rank-16 update of the other tiles
@@ -444,9 +556,18 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) dA[kc] = S.P[lc][4 * kc + lr];      // A operand: D^-1 (row lc, k = 4 kc + lr)
             const bool partial = bs < GP_B;
-            for (int blk = 0;; ++blk) {
-                const int pos = (blk & 1) ? NW - 1 - w : w;
-                const int i = nt - 1 - (blk * NW + pos);
+            // look-ahead (wavefront 0): the next pivot block, tile (kt + 1, kt + 1) after this step
+            const int rest = n - (k0 + GP_B);
+            const bool la = kLookAhead && rest > 0;
+            if (la && w == 0) {
+                const gp_v4f64 wn = w_alayout(dA, S.V, kt + 1);
+                KP Tn = A + tile_base(kt + 1, kt + 1);
+                const gp_v4f64 c = rank16(load_tile(Tn), wn, S.V, kt + 1);
+                store_tile(Tn, c);
+                stage_invert(c, (rest < GP_B) ? rest : GP_B, pn1);
+            }
+            for (;;) {
+                const int i = grab_row();
                 if (i < 0) break;
                 if (i == kt && !partial) {
                     // the whole tile row is pivot rows: its off-diagonal tiles are written by the owners of
@@ -485,7 +606,7 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
                         const int j = j0 + u;
-                        on[u] = (j <= i) && (j != kt || i == kt);
+                        on[u] = (j <= i) && (j != kt || i == kt) && !(la && i == kt + 1 && j == kt + 1);
                         const int jj = (j <= i) ? j : i;
                         KP T = A + tile_base(i, jj);
 #pragma unroll
@@ -516,6 +637,8 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
             }
             W::sync();
             GP_T(8);
+            have1 = la;
+            have2 = false;
             ++kt;
             k0 += GP_B;
         }

@@ -824,6 +824,13 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)num_cus(dev) * per_cu;
     if (GLOBAL_K && grid > gp_grid_cap<NP>::G) grid = gp_grid_cap<NP>::G;
+    {
+        // tuning knob: LCFE_GP_GRID_<rows>=k caps the workgroups of a tier (fewer Gram matrices in flight = more of them in L2)
+        char name[40];
+        snprintf(name, sizeof name, "LCFE_GP_GRID_%d", NP);
+        const char* e = getenv(name);
+        if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e);
+    }
     if (grid > B.n_obj) grid = B.n_obj;
     if (grid < 1) return 0;
     hipLaunchKernelGGL((gp_kernel<NP, GLOBAL_K>), dim3((unsigned)grid), dim3(threads), 0, stream, B, bins, bin, nan_from,
@@ -881,12 +888,12 @@ constexpr int kGp1dThreads = 256;       // measured: 64 threads 10.1 s, 128: 7.2
 // after the other on the whole workgroup with the NP-row matrix.  Both layouts share one LDS buffer.
 template <int WNP>
 struct Gp1dWaveLds {
-    GpLds<WNP, 1> S;
+    Gp1dLds<WNP, 1> S;
     double K[gp_store_doubles(WNP)];
 };
 template <int NP, int NW>
 struct Gp1dBlockLds {
-    GpLds<NP, NW> S;
+    Gp1dLds<NP, NW> S;
     double K[gp_store_doubles(NP)];
 };
 
@@ -1014,8 +1021,8 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
         // in this workgroup's slab of global scratch; the working set of a kGp1dLongNP-row fit aliases the LDS buffer
         if constexpr (ROWCAP > NP) {
             if (kslab != nullptr && most + 1 > NP) {
-                static_assert(sizeof(GpLds<kGp1dLongNP, W::NWAVES>) <= sizeof(raw), "long-band working set must fit the LDS buffer");
-                auto& LG = *reinterpret_cast<GpLds<kGp1dLongNP, W::NWAVES>*>(raw);
+                static_assert(sizeof(Gp1dLds<kGp1dLongNP, W::NWAVES>) <= sizeof(raw), "long-band working set must fit the LDS buffer");
+                auto& LG = *reinterpret_cast<Gp1dLds<kGp1dLongNP, W::NWAVES>*>(raw);
                 double* Kg = kslab + (size_t)blockIdx.x * (size_t)gp_store_doubles(kGp1dLongNP);
                 for (int j = 0; j < 4; ++j) {
                     if (nvalid[j] + 1 <= NP) continue;

@@ -94,7 +94,7 @@ extern "C" int hostsim_gp1d(int64_t n_obj, const int64_t* offsets, const double*
     using W = WaveHost;
     constexpr int NP = 256;
     auto obj = std::make_unique<ObjLds<HOSTSIM_CAP>>();
-    auto ws = std::make_unique<GpLds<NP, 1>>();
+    auto ws = std::make_unique<Gp1dLds<NP, 1>>();
     std::vector<double> K((size_t)gp_store_doubles(NP));
     for (int64_t i = 0; i < n_obj; ++i) {
         const int64_t s = offsets[i];
