@@ -105,6 +105,11 @@ int lcfe_extract(int mask, int device, int64_t n_obj, const int64_t* offsets, co
  *              `stream` has completed -- concurrent calls need separate workspaces
  */
 size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points);
+/* ... plus the slabs of the long-object tier for a batch whose longest light curve has max_len rows: light curves beyond
+ * the LDS tiers (2048 rows; 1024 for the object-level fits and the research set; 767 for the 2-D GP) run with their
+ * working set in global scratch, up to lcfe_max_points() rows / lcfe_gp2d_max_points() valid points.  A call whose
+ * workspace holds only lcfe_workspace_bytes() leaves such objects NaN with status -100. */
+size_t lcfe_workspace_bytes_for(int mask, int64_t n_obj, int64_t n_points, int64_t max_len);
 int lcfe_extract_device(int mask, int device, void* stream, int64_t n_obj, int64_t n_points,
                         int64_t max_len, const int64_t* d_offsets, const double* d_t,
                         const double* d_flux, const double* d_err, const uint8_t* d_band,
@@ -115,7 +120,7 @@ int lcfe_extract_device(int mask, int device, void* stream, int64_t n_obj, int64
  * this releases them */
 void lcfe_release_buffers(void);
 
-/* largest number of points per object any kernel tier accepts */
+/* largest number of points per object any kernel tier accepts (the long-object tier) */
 int64_t lcfe_max_points(void);
 /* largest number of VALID points (known band, finite flux and error, error > 0) per object the 2-D GP accepts */
 int64_t lcfe_gp2d_max_points(void);

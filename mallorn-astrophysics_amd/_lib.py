@@ -85,6 +85,8 @@ def load():
     lib.lcfe_implemented_mask.restype = ctypes.c_int
     lib.lcfe_workspace_bytes.restype = ctypes.c_size_t
     lib.lcfe_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+    lib.lcfe_workspace_bytes_for.restype = ctypes.c_size_t
+    lib.lcfe_workspace_bytes_for.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     lib.lcfe_extract.restype = ctypes.c_int
     lib.lcfe_extract.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_i64p, c_f64p, c_f64p, c_f64p,
                                  c_u8p, c_f64p, c_f64p, c_i32p, ctypes.POINTER(LcfeStats)]

@@ -118,7 +118,7 @@ template <> struct FitPolicy<WaveDev> { using type = GroupDev<8>; };
 
 template <class W, int CAP>
 struct RunSet<W, SET_STAT, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_STAT, CAP>& ws, double* row, int32_t*) {
         LCFE_PT0();
         stage_object<W, CAP>(in, ws.obj);
         LCFE_PT(0);
@@ -127,74 +127,82 @@ struct RunSet<W, SET_STAT, CAP> {
         store_row<W>(ws.stat.out, row, STAT_NCOL);
         W::sync();
         LCFE_PT(3);
+        return 0;
     }
 };
 
 template <class W, int CAP>
 struct RunSet<W, SET_BAZIN, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_BAZIN, CAP>& ws, double* row, int32_t* st) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_BAZIN, CAP>& ws, double* row, int32_t* st) {
         stage_object<W, CAP>(in, ws.obj);
         bazin_object<typename FitPolicy<W>::type, W, CAP>(ws.obj, ws.fit, st);
         store_row<W>(ws.fit.out, row, BAZIN_NCOL);
         W::sync();
+        return 0;
     }
 };
 
 template <class W, int CAP>
 struct RunSet<W, SET_POWERLAW, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_POWERLAW, CAP>& ws, double* row, int32_t* st) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_POWERLAW, CAP>& ws, double* row, int32_t* st) {
         stage_object<W, CAP>(in, ws.obj);
         powerlaw_object<typename FitPolicy<W>::type, W, CAP>(ws.obj, ws.fit, st);
         store_row<W>(ws.fit.out, row, POWERLAW_NCOL);
         W::sync();
+        return 0;
     }
 };
 
 template <class W, int CAP>
 struct RunSet<W, SET_TDE, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_TDE, CAP>& ws, double* row, int32_t*) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_TDE, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
         tde_object<W, CAP>(ws.obj, ws.s);
         store_row<W>(ws.s.out, row, TDE_NCOL);
         W::sync();
+        return 0;
     }
 };
 template <class W, int CAP>
 struct RunSet<W, SET_COLOR, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_COLOR, CAP>& ws, double* row, int32_t*) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_COLOR, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
         color_object<W, CAP>(ws.obj, ws.s);
         store_row<W>(ws.s.out, row, COLOR_NCOL);
         W::sync();
+        return 0;
     }
 };
 template <class W, int CAP>
 struct RunSet<W, SET_SHAPE, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_SHAPE, CAP>& ws, double* row, int32_t*) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_SHAPE, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
         shape_object<W, typename FitPolicy<W>::type, CAP>(ws.obj, ws.s);
         store_row<W>(ws.s.out, row, SHAPE_NCOL);
         W::sync();
+        return 0;
     }
 };
 template <class W, int CAP>
 struct RunSet<W, SET_PHYSICS, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_PHYSICS, CAP>& ws, double* row, int32_t*) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_PHYSICS, CAP>& ws, double* row, int32_t*) {
         stage_object<W, CAP>(in, ws.obj);
         physics_object<W, CAP>(ws.obj, in.z, ws.s);
         store_row<W>(ws.s.out, row, PHYSICS_NCOL);
         W::sync();
+        return 0;
     }
 };
 
 template <class W, int CAP>
 struct RunSet<W, SET_RESEARCH, CAP> {
-    static LCFE_FN void run(const ObjIn& in, SetLds<SET_RESEARCH, CAP>& ws, double* row, int32_t* st) {
+    static LCFE_FN int run(const ObjIn& in, SetLds<SET_RESEARCH, CAP>& ws, double* row, int32_t* st) {
         stage_object<W, CAP>(in, ws.obj);
         const int rc = research_object<W, CAP>(ws.obj, in.z, ws.s);
         if (st && W::lane() == 0) st[0] = rc;
         store_row<W>(ws.s.out, row, RESEARCH_NCOL);
         W::sync();
+        return rc;
     }
 };
 

@@ -82,10 +82,11 @@ template <int NP, int LDV> struct GpSmallArrays<NP, LDV, true> {
 template <bool ON> struct GpStageTile { double stage[1]; };
 template <> struct GpStageTile<true> { double stage[GP_B * GP_B]; };
 
-template <int NP, int NW = 4, bool FUSE = false, bool LOOKAHEAD = true>
+template <int NP, int NW = 4, bool FUSE = false, bool LOOKAHEAD = true, bool IN_LDS = true>
 struct GpLds {
     static constexpr bool kFuse = FUSE;
     static constexpr bool kLookAhead = LOOKAHEAD && NW >= 4;
+    static constexpr bool kInLds = IN_LDS;    // false: the long-object tier keeps this working set in global scratch
     double t[NP], y[NP], e2[NP];              // valid points: time (from first valid), flux/scale, (err/scale)^2
     double alpha[NP];                         // K^-1 r
     GpSmallArrays<NP, gp_panel_ld(NP), FUSE> sm;
@@ -291,10 +292,14 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
         constexpr bool kLookAhead = LDS::kLookAhead;
         double pn1[4] = {0, 0, 0, 0}, pn2[4] = {0, 0, 0, 0};      // wavefront 0: -(-D^-1) of the next pivot block(s), Gauss-Jordan layout
         bool have1 = false, have2 = false;                         // (uniform) the next step's inverse(s) are already known
-        auto* row_ticket = (__attribute__((address_space(3))) int*)(&S.row_ticket);
         auto grab_row = [&]() -> int {
             int r = 0;
-            if (l == 0) r = __hip_atomic_fetch_add(row_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (l == 0) {
+                if constexpr (LDS::kInLds)
+                    r = __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&S.row_ticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    r = __hip_atomic_fetch_add(&S.row_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             return nt - 1 - __builtin_amdgcn_readfirstlane(r);
         };
         // tile in D layout -> Gauss-Jordan layout through the staging tile (lower half mirrored, identity padding beyond

@@ -72,7 +72,7 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 9;
+constexpr int kNumLists = 2 * kNumBins + 12;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
@@ -82,6 +82,9 @@ constexpr int kStatL32List = 2 * kNumBins + 5;        // ... 32-row lanes (r, i:
 constexpr int kStatL32xList = 2 * kNumBins + 6;       // light curves of up to 256 rows whose bands fit 32-row lanes
 constexpr int kStatW16List = 2 * kNumBins + 7;        // ... up to 256 rows, 32-row lanes with 16 lanes per light curve (bands of up to 64 rows, r, i: 128)
 constexpr int kStatW32List = 2 * kNumBins + 8;        // ... up to 512 rows, the same
+constexpr int kBazinLongList = 2 * kNumBins + 9;      // light curves of more than 1024 rows with a band beyond the largest fit tier
+constexpr int kPowerlawLongList = 2 * kNumBins + 10;  // ... with more post-peak rows in a band than the largest fit tier
+constexpr int kResearchLongList = 2 * kNumBins + 11;  // light curves whose r band spans more days than the Mexican-hat grid in LDS
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -208,7 +211,15 @@ __global__ __launch_bounds__(64, (set_waves<SET, CAP>::N)) void set_kernel(Batch
             int32_t* st = (status && nst) ? status + i * (int64_t)st_ld + st0 : nullptr;
             ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, n, B.z ? B.z[i] : qnan()};
             LCFE_PT(5);
-            RunSet<W, SET, CAP>::run(in, ws, row, st);
+            const int rc = RunSet<W, SET, CAP>::run(in, ws, row, st);
+            if constexpr (SET == SET_RESEARCH) {
+                // r band longer than the Mexican-hat grid of this tier: the long-object tier takes the light curve
+                if (rc == -100 && threadIdx.x == 0) {
+                    const int slot = atomicAdd(&bins.counts[kResearchLongList], 1);
+                    bins.lists[(int64_t)kResearchLongList * bins.stride + slot] = (int)i;
+                }
+            }
+            (void)rc;
             LCFE_PT0B();
         }
     }
@@ -273,6 +284,62 @@ __global__ __launch_bounds__(64, stat_lean_waves<CAP>::N) void stat_lean_kernel(
     }
     LCFE_PT(5);
     LCFE_PT_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The long-object tier.  The reference has no limit on the rows of a light curve; the LDS tiers end at 2048 rows
+// (1024 for the object-level fits and the research set).  Longer light curves -- and the ones that overflow a per-band
+// limit of the LDS tiers -- run through the SAME templates with CAP = kLongCap, their working set (the structures that
+// are LDS in the tiers) in a per-workgroup slab of global scratch: one wavefront per workgroup, a handful of workgroups
+// (such objects are rare; the reference's own loaders truncate light curves at 300-500 points).  Up to three index
+// lists are drained through one ticket counter.  Light curves beyond kLongCap rows keep NaN and status -100.
+constexpr int kLongCap = 16384;
+constexpr int kLongGrid = 16;
+template <int SET> constexpr size_t long_slab_bytes() { return (sizeof(SetLds<SET, kLongCap>) + 255) & ~(size_t)255; }
+
+template <int SET>
+__global__ __launch_bounds__(64) void set_long_kernel(BatchView B, Bins bins, int l0, int l1, int l2, double* out, int ld, int col0,
+                                                      int32_t* status, int st_ld, int st0, unsigned long long* ticket, char* slabs) {
+    using W = LongDev;
+    __shared__ long long next_ticket;
+    SetLds<SET, kLongCap>& ws = *reinterpret_cast<SetLds<SET, kLongCap>*>(slabs + (size_t)blockIdx.x * long_slab_bytes<SET>());
+    const int ncol = set_ncols(SET), nst = set_nstatus(SET);
+    const int c0 = (l0 >= 0) ? bins.counts[l0] : 0, c1 = (l1 >= 0) ? bins.counts[l1] : 0, c2 = (l2 >= 0) ? bins.counts[l2] : 0;
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t pos = next_ticket;
+        __syncthreads();
+        if (pos >= (int64_t)c0 + c1 + c2) break;
+        const int li = (pos < c0) ? l0 : ((pos < (int64_t)c0 + c1) ? l1 : l2);
+        const int64_t at = (pos < c0) ? pos : ((pos < (int64_t)c0 + c1) ? pos - c0 : pos - c0 - c1);
+        // (wave-uniform by construction; said explicitly, so that the branch on the length below is a scalar branch --
+        //  as a divergent `continue` the compiler turned it into an inner loop that re-read the same ticket for ever)
+        const int64_t i = __builtin_amdgcn_readfirstlane(bins.lists[(int64_t)li * bins.stride + at]);
+        const int64_t s = B.offsets[i];
+        const int64_t n = B.offsets[i + 1] - s;
+        double* row = out + i * (int64_t)ld + col0;
+        int32_t* st = (status && nst) ? status + i * (int64_t)st_ld + st0 : nullptr;
+        const bool fits = __builtin_amdgcn_readfirstlane((int)(n <= kLongCap)) != 0;
+        if (fits) {
+            ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n, B.z ? B.z[i] : qnan()};
+            RunSet<W, SET, kLongCap>::run(in, ws, row, st);
+        } else {
+            fill_row_nan<W>(row, ncol);
+            if (st) for (int k = threadIdx.x; k < nst; k += 64) st[k] = -100;
+        }
+        __syncthreads();
+    }
+}
+
+template <int SET>
+int launch_long(const BatchView& B, const Bins& bins, int l0, int l1, int l2, double* out, int ld, int col0, int32_t* status, int st_ld,
+                int st0, hipStream_t stream, unsigned long long* ticket, char* slabs) {
+    if (!slabs) return 0;
+    hipLaunchKernelGGL(set_long_kernel<SET>, dim3(kLongGrid), dim3(64), 0, stream, B, bins, l0, l1, l2, out, ld, col0, status, st_ld, st0,
+                       ticket, slabs);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // Statistics, eight light curves per wavefront and one lane per band (stat_lanes.hpp: CAP = rows of u, g, z, y a lane
@@ -489,8 +556,13 @@ __global__ __launch_bounds__(64, 2) void bazin_partition_kernel(BatchView B, Bin
                         bins.lists[(int64_t)kBazinFallbackList * bins.stride + slot] = (int)i;
                     }
                 } else {
+                    // the long-object tier takes it (when the caller's workspace has its slabs); NaN and -100 until then
                     fill_row_nan<W>(out + i * (int64_t)ld + col0, BAZIN_NCOL);
                     if (status && threadIdx.x < 12) status[i * (int64_t)st_ld + st0 + threadIdx.x] = -100;
+                    if (threadIdx.x == 0) {
+                        const int slot = atomicAdd(&bins.counts[kBazinLongList], 1);
+                        bins.lists[(int64_t)kBazinLongList * bins.stride + slot] = (int)i;
+                    }
                 }
             } else if (threadIdx.x < 6) {
                 const int b = threadIdx.x;
@@ -659,6 +731,10 @@ __global__ __launch_bounds__(64, 2) void powerlaw_partition_kernel(BatchView B, 
                 } else {
                     fill_row_nan<W>(out + i * (int64_t)ld + col0, POWERLAW_NCOL);
                     if (status && threadIdx.x < 54) status[i * (int64_t)st_ld + st0 + threadIdx.x] = -100;
+                    if (threadIdx.x == 0) {
+                        const int slot = atomicAdd(&bins.counts[kPowerlawLongList], 1);
+                        bins.lists[(int64_t)kPowerlawLongList * bins.stride + slot] = (int)i;
+                    }
                 }
             } else if (threadIdx.x < 3) {
                 const int j = threadIdx.x;
@@ -778,6 +854,16 @@ template <int NP> struct gp_grid_cap { static constexpr int G = (NP == 112) ? kG
 // so their register budget is halved (the L-BFGS-B driver spills a little, the sweep does not)
 template <int NP, bool GLOBAL_K> struct gp_waves { static constexpr int N = (NP <= 64) ? 3 : (GLOBAL_K ? ((NP == 512) ? 2 : 4) : 2); };
 
+// the long-object tier of the 2-D GP: light curves of more than 767 rows, up to kGpLongNP - 1 valid points; Gram matrix AND
+// working set (panels, point arrays, optimiser state) in per-workgroup slabs of global scratch
+constexpr int kGpLongNP = 2048;
+constexpr int kGpLongGrid = 8;
+// (no pivot look-ahead: its staging tile is handed over between lanes of one wavefront under wave-level fences, which the
+//  tiers rely on for LDS only)
+template <int NP> struct gp_working_set { using type = GpLds<NP, gp_threads<NP>::T / 64, false, false, false>; };
+constexpr size_t kGpLongSBytes = (sizeof(gp_working_set<kGpLongNP>::type) + 255) & ~(size_t)255;
+constexpr size_t kGpLongBytes = (size_t)kGpLongGrid * ((size_t)gp_store_doubles(kGpLongNP) * 8 + kGpLongSBytes);
+
 template <int NP, bool GLOBAL_K>
 __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) void gp_kernel(BatchView B, Bins bins, int bin, int nan_from, double* out, int ld,
                                                  int col0, int32_t* status, int st_ld, int st0, double* kscratch,
@@ -814,6 +900,36 @@ __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) voi
     nan_fill_bins<W>(bins, 1, nan_from, out, ld, col0, GP_NCOL, status, st_ld, st0, 4);
 }
 
+// the same loop for the long-object tier (slabs: kGpLongGrid Gram matrices, then kGpLongGrid working sets)
+__global__ __launch_bounds__(gp_threads<kGpLongNP>::T, 1) void gp_long_kernel(BatchView B, Bins bins, int bin, double* out, int ld, int col0,
+                                                                             int32_t* status, int st_ld, int st0, char* slabs,
+                                                                             unsigned long long* ticket) {
+    constexpr int NP = kGpLongNP;
+    using W = BlockDev<gp_threads<NP>::T>;
+    using SL = gp_working_set<NP>::type;
+    __shared__ long long next_ticket;
+    double* Kg = reinterpret_cast<double*>(slabs) + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
+    SL& S = *reinterpret_cast<SL*>(slabs + (size_t)kGpLongGrid * gp_store_doubles(NP) * 8 + (size_t)blockIdx.x * kGpLongSBytes);
+    const int count = bins.counts[kNumBins + bin];
+    const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
+    for (;;) {
+        if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t pos = next_ticket;
+        __syncthreads();
+        if (pos >= count) break;
+        const int64_t i = list[pos];
+        const int64_t s = B.offsets[i];
+        const int64_t n64 = B.offsets[i + 1] - s;
+        int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
+        ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
+        gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
+            gp_eval<W, NP, double*>(x, n, S, Kg, f, g, need); }, st);
+        store_row<W>(S.out, out + i * (int64_t)ld + col0, GP_NCOL);
+        __syncthreads();
+    }
+}
+
 template <int NP, bool GLOBAL_K>
 int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
                    int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, double* kscratch,
@@ -841,7 +957,7 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
 
 int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
               int st_ld, int st0, hipStream_t stream, hipStream_t stream2, int dev, double* kscratch,
-              size_t kscratch_bytes, int* n_launch, unsigned long long* tickets) {
+              size_t kscratch_bytes, int* n_launch, unsigned long long* tickets, char* long_slabs) {
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
@@ -872,6 +988,13 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
         }
         if (rc) return rc;
         ++*n_launch;
+        // light curves of more than 767 rows (bin 6; NaN rows and status -100 from the launch above until this one has run)
+        if (ti == last && last == 5 && long_slabs) {
+            hipLaunchKernelGGL(gp_long_kernel, dim3(kGpLongGrid), dim3(gp_threads<kGpLongNP>::T), 0, q, B, bins, 6, out, ld, col0, status,
+                               st_ld, st0, long_slabs, tickets + SET_GP2D * 8 + 7);
+            HIP_TRY(hipGetLastError());
+            ++*n_launch;
+        }
     }
     return 0;
 }
@@ -1128,7 +1251,7 @@ constexpr int max_tier() {
 
 template <int SET>
 int launch_set(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
-               int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets) {
+               int st_ld, int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, char* long_slabs) {
     // tiers needed: every tier whose window (prev_cap, cap] can contain an object, i.e. up to the
     // first cap >= max_len; the last launched tier also NaN-fills the bins of longer objects.
     int last = 0;
@@ -1147,6 +1270,14 @@ int launch_set(const BatchView& B, const Bins& bins, int64_t max_len, double* ou
                     rc = launch_tier<SET, 2048>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, stream, dev, tk);
                 break;
         }
+        if (rc) return rc;
+        ++*n_launch;
+    }
+    // the long-object tier: bin 6 (more than 2048 rows); the research set's LDS tiers end at 1024 rows (bin 4 too) and at
+    // 4096 days of r band (its overflow list)
+    if (long_slabs && (max_len > kTiers[max_tier<SET>()] || SET == SET_RESEARCH)) {
+        const int rc = launch_long<SET>(B, bins, 6, (SET == SET_RESEARCH) ? 4 : -1, (SET == SET_RESEARCH) ? kResearchLongList : -1, out, ld, col0,
+                                        status, st_ld, st0, stream, tickets + SET * 8 + 7, long_slabs);
         if (rc) return rc;
         ++*n_launch;
     }
@@ -1203,7 +1334,7 @@ int launch_bazin_fits(const BatchView& B, const Bins& bins, const FitWs& F, int 
 // kernel for objects with a band beyond the largest fit tier, then the cross-band columns.
 int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
                  int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, void* ws, size_t ws_bytes,
-                 int64_t n_points) {
+                 int64_t n_points, char* long_slabs) {
     if (!ws || ws_bytes < bazin_ws_bytes(B.n_obj, n_points))
         return fail_msg("lcfe_extract_device: workspace too small for the Bazin fit lists");
     const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)B.n_obj;
@@ -1246,6 +1377,12 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
     hipLaunchKernelGGL(bazin_cross_kernel, dim3((unsigned)((B.n_obj + 255) / 256)), dim3(256), 0, stream, B, out, ld, col0);
     HIP_TRY(hipGetLastError());
     ++*n_launch;
+    // the long-object tier: more than 2048 rows (bin 6), or more than 1024 rows with a band beyond the fit tiers (all 52 columns)
+    if (long_slabs && max_len > 1024) {
+        rc = launch_long<SET_BAZIN>(B, bins, 6, kBazinLongList, -1, out, ld, col0, status, st_ld, st0, stream, tk + 7, long_slabs);
+        if (rc) return rc;
+        ++*n_launch;
+    }
     return 0;
 }
 
@@ -1289,7 +1426,7 @@ int launch_powerlaw_fits(const BatchView& B, const Bins& bins, const PlWs& F, in
 
 int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status, int st_ld,
                     int st0, hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, void* ws, size_t ws_bytes,
-                    int64_t n_points) {
+                    int64_t n_points, char* long_slabs) {
     if (!ws || ws_bytes < powerlaw_ws_bytes(B.n_obj, n_points))
         return fail_msg("lcfe_extract_device: workspace too small for the decline-fit lists");
     const size_t np = (size_t)(n_points > 0 ? n_points : 1), no = (size_t)B.n_obj;
@@ -1331,6 +1468,11 @@ int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, doubl
     rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
     if (rc) return rc;
     ++*n_launch;
+    if (long_slabs && max_len > 1024) {
+        rc = launch_long<SET_POWERLAW>(B, bins, 6, kPowerlawLongList, -1, out, ld, col0, status, st_ld, st0, stream, tk + 7, long_slabs);
+        if (rc) return rc;
+        ++*n_launch;
+    }
     return 0;
 }
 
@@ -1373,7 +1515,7 @@ static bool stat_lanes_enabled() {
 // Statistics: lean kernels for the tiers up to 512 rows, the general kernel for the longer tiers,
 // for the lean kernels' fallback list and for the NaN rows of over-long objects.
 int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0,
-                hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, hipStream_t s1, hipStream_t s2) {
+                hipStream_t stream, int dev, int* n_launch, unsigned long long* tickets, hipStream_t s1, hipStream_t s2, char* long_slabs) {
     int last = 0;
     while (last < 4 && kTiers[last] < max_len) ++last;
     unsigned long long* tk = tickets + SET_STAT * 8;
@@ -1450,6 +1592,11 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
     else rc = launch_tier<SET_STAT, 512>(B, bins, kStatFallbackList, nan_from, out, ld, col0, nullptr, 0, 0, stream, dev, tk + 5, fb_grid);
     if (rc) return rc;
     ++*n_launch;
+    if (long_slabs && max_len > kMaxPoints) {
+        rc = launch_long<SET_STAT>(B, bins, 6, -1, -1, out, ld, col0, nullptr, 0, 0, stream, tk + 7, long_slabs);
+        if (rc) return rc;
+        ++*n_launch;
+    }
     return 0;
 }
 
@@ -1518,9 +1665,9 @@ int lcfe_device_count(void) {
 
 const char* lcfe_last_error(void) { return g_err.c_str(); }
 
-int64_t lcfe_max_points(void) { return kMaxPoints; }
+int64_t lcfe_max_points(void) { return kLongCap; }
 
-int64_t lcfe_gp2d_max_points(void) { return kGpGlobalNP - 1; }
+int64_t lcfe_gp2d_max_points(void) { return kGpLongNP - 1; }
 
 int lcfe_implemented_mask(void) {
     int m = 0;
@@ -1565,6 +1712,29 @@ size_t lcfe_workspace_bytes(int mask, int64_t n_obj, int64_t n_points) {
     if (mask & (1 << SET_BAZIN)) b += bazin_ws_bytes(n_obj, n_points);
     if (mask & (1 << SET_POWERLAW)) b += powerlaw_ws_bytes(n_obj, n_points);
     if (mask & (1 << SET_GP1D)) b += kGp1dLongBytes;
+    return b;
+}
+
+// slabs of the long-object tier of one set (0: the set needs none for light curves of up to max_len rows)
+static size_t long_bytes_of(int set, int64_t max_len) {
+    switch (set) {
+        case SET_STAT: return (max_len > kMaxPoints) ? kLongGrid * long_slab_bytes<SET_STAT>() : 0;
+        case SET_BAZIN: return (max_len > 1024) ? kLongGrid * long_slab_bytes<SET_BAZIN>() : 0;
+        case SET_POWERLAW: return (max_len > 1024) ? kLongGrid * long_slab_bytes<SET_POWERLAW>() : 0;
+        case SET_TDE: return (max_len > kMaxPoints) ? kLongGrid * long_slab_bytes<SET_TDE>() : 0;
+        case SET_COLOR: return (max_len > kMaxPoints) ? kLongGrid * long_slab_bytes<SET_COLOR>() : 0;
+        case SET_SHAPE: return (max_len > kMaxPoints) ? kLongGrid * long_slab_bytes<SET_SHAPE>() : 0;
+        case SET_PHYSICS: return (max_len > kMaxPoints) ? kLongGrid * long_slab_bytes<SET_PHYSICS>() : 0;
+        case SET_GP2D: return (max_len > kGpGlobalNP - 1) ? kGpLongBytes : 0;
+        case SET_RESEARCH: return kLongGrid * long_slab_bytes<SET_RESEARCH>();     // (an r band of more than 4096 days can sit in a short light curve)
+    }
+    return 0;
+}
+
+size_t lcfe_workspace_bytes_for(int mask, int64_t n_obj, int64_t n_points, int64_t max_len) {
+    size_t b = lcfe_workspace_bytes(mask, n_obj, n_points);
+    for (int s = 0; s < NUM_SETS; ++s)
+        if (mask & (1 << s)) b += long_bytes_of(s, max_len);
     return b;
 }
 
@@ -1620,6 +1790,15 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
     const size_t pl_bytes = pl_ws ? powerlaw_ws_bytes(n_obj, n_points) : 0;
     region += pl_bytes;
     double* gp1d_slab = (mask & (1 << SET_GP1D)) ? (double*)region : nullptr;
+    if (gp1d_slab) region += kGp1dLongBytes;
+    // the slabs of the long-object tier, when the workspace was sized with lcfe_workspace_bytes_for(.., max_len)
+    char* long_slab[NUM_SETS] = {};
+    if (workspace_bytes >= lcfe_workspace_bytes_for(mask, n_obj, n_points, max_len)) {
+        for (int s = 0; s < NUM_SETS; ++s) {
+            const size_t lb = (mask & (1 << s)) ? long_bytes_of(s, max_len) : 0;
+            if (lb) { long_slab[s] = region; region += lb; }
+        }
+    }
     const Bins bins{lists, counts, n_obj};
     // Launch plan.  The sets write disjoint columns and only read the bins, so after the shared prologue
     // (+ the statistics set, which stays alone so that its event time is a clean roofline sample) the
@@ -1685,19 +1864,19 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if (prof && ne != 0) HIP_TRY(hipEventRecord(ev0[s], q));
         int nl = 0, rc = 0;
         switch (s) {
-            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets, fork ? side[0] : q, fork ? side[1] : q); break;
-            case SET_BAZIN: rc = launch_bazin(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, bazin_ws, bazin_bytes, n_points); break;
-            case SET_POWERLAW: rc = launch_powerlaw(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, pl_ws, pl_bytes, n_points); break;
-            case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
-            case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
-            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
-            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
-            case SET_RESEARCH: rc = launch_set<SET_RESEARCH>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets); break;
+            case SET_STAT: rc = launch_stat(B, bins, max_len, d_out, ld, col0, q, dev, &nl, tickets, fork ? side[0] : q, fork ? side[1] : q, long_slab[s]); break;
+            case SET_BAZIN: rc = launch_bazin(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, bazin_ws, bazin_bytes, n_points, long_slab[s]); break;
+            case SET_POWERLAW: rc = launch_powerlaw(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, pl_ws, pl_bytes, n_points, long_slab[s]); break;
+            case SET_TDE: rc = launch_set<SET_TDE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
+            case SET_COLOR: rc = launch_set<SET_COLOR>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
+            case SET_SHAPE: rc = launch_set<SET_SHAPE>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
+            case SET_PHYSICS: rc = launch_set<SET_PHYSICS>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
+            case SET_RESEARCH: rc = launch_set<SET_RESEARCH>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
             case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, gp1d_slab); break;
             case SET_GP2D:
                 if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }
                 rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, fork ? side[2] : q, dev, gp_scratch,
-                               gp_scratch_bytes, &nl, tickets);
+                               gp_scratch_bytes, &nl, tickets, long_slab[s]);
                 // the set's stop event (prof) is recorded on q: make q wait for the tiers on the second stream
                 if (fork) {
                     hipEvent_t half;
@@ -1766,7 +1945,7 @@ int lcfe_extract(int mask, int device, int64_t n_obj, const int64_t* offsets, co
     HostPathPool& P = g_pool[dev];
     std::lock_guard<std::mutex> pool_lock(P.mutex);
     const size_t npa = (size_t)(np > 0 ? np : 1);
-    const size_t wsb = lcfe_workspace_bytes(mask, n_obj, np);
+    const size_t wsb = lcfe_workspace_bytes_for(mask, n_obj, np, max_len);
     const size_t need[HostPathPool::NBUF] = {sizeof(int64_t) * (size_t)(n_obj + 1), 8 * npa, 8 * npa, 8 * npa, npa,
                                              z ? 8 * (size_t)n_obj : 0, 8 * (size_t)n_obj * (size_t)ld,
                                              st_ld > 0 ? 4 * (size_t)n_obj * (size_t)st_ld : 0, wsb};

@@ -14,14 +14,16 @@
 namespace lcfe {
 
 constexpr int RESEARCH_NCOL = 40;
-constexpr int RESEARCH_GRID = 4096;       // longest 1-day grid of the r band the MHPS pass takes (days of time span)
+// longest 1-day grid of the r band the MHPS pass takes (days of time span): 32 KiB of LDS in the LDS tiers, 512 KiB of
+// global scratch in the long-object tier (CAP > 2048)
+template <int CAP> constexpr int research_grid() { return (CAP > 2048) ? 65536 : 4096; }
 constexpr int RESEARCH_WAVELET = 500;     // 5 x the largest scale (100 d)
 
 template <int CAP>
 struct ResearchLds {
     double xs[CAP], ys[CAP], zs[CAP];
     unsigned long long keys[CAP];
-    double grid[RESEARCH_GRID];
+    double grid[research_grid<CAP>()];
     double wv[RESEARCH_WAVELET];
     double slot[4];
     double out[RESEARCH_NCOL];
@@ -254,7 +256,7 @@ LCFE_FN bool research_mhps(const double* t, const double* f, int m, ResearchLds<
     const double span = t[m - 1] - t[0];
     if (!(span >= 50)) return true;                                 // :387 (NaN span: `time_span < 50` is False in the reference, but its arange then raises)
     const double nd = ceil(span);                                   // len(np.arange(t0, t_last, 1.0))
-    if (!(nd <= (double)RESEARCH_GRID)) return false;
+    if (!(nd <= (double)research_grid<CAP>())) return false;
     const int N = (int)nd;
     // np.interp on the regular grid (:391-394): x_k = t0 + k
     // np.arange fills start, start + step, then start + k * delta with delta = (start + step) - start -- not exactly 1

@@ -132,6 +132,21 @@ struct WaveDev {
 #endif
 
 #if defined(__HIPCC__)
+// The wavefront of the long-object tier: WaveDev with the object's working set in GLOBAL scratch instead of LDS.  Every
+// hand-over between lanes goes through memory the vector caches sit in front of, so every fence -- also the ones that
+// are wave-level for LDS -- waits for the stores at workgroup scope; the per-band passes run one after the other on the
+// whole wavefront (FitPolicy<LongDev> = LongDev) instead of side by side in lane groups.
+struct LongDev : WaveDev {
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    static __device__ __forceinline__ void wave_sync() { sync(); }
+};
+#endif
+
+#if defined(__HIPCC__)
 // GS consecutive lanes of a wavefront working on ONE fit while the other groups of the same wave
 // work on other fits (the bands of one light curve).  Groups diverge freely: nothing here uses a
 // wave-wide collective or a hardware barrier.  Reductions are DPP moves inside an 8-lane group

@@ -108,7 +108,7 @@ class DeviceBatch:
         if nst and not (status.is_contiguous() and tuple(status.shape) == (self.n_obj, nst)
                         and status.dtype == torch.int32 and status.device == self.device):
             raise ValueError(f"status must be a contiguous int32 [{self.n_obj}, {nst}] tensor on {self.device}")
-        wsb = lib.lcfe_workspace_bytes(mask, self.n_obj, self.n_points)
+        wsb = lib.lcfe_workspace_bytes_for(mask, self.n_obj, self.n_points, self.max_len)
         if self._ws is None or self._ws.numel() < wsb:
             self._ws = torch.empty(int(wsb), dtype=torch.uint8, device=self.device)
         st = _lib.LcfeStats()

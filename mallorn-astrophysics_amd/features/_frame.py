@@ -26,25 +26,24 @@ NEEDS_Z = {"physics", "research"}
 
 def _limit_message(set_name, csr, rows, lib):
     """What the objects `rows` of a set ran into (status -100): the message names the limit that was hit, so that a
-    limit-NaN can be told from a failed fit."""
+    limit-NaN can be told from a failed fit.  The LDS tiers end at 2048 rows (1024 for the object-level fits and the
+    research set, 767 for the 2-D GP); longer light curves run in the long-object tier (working set in global scratch),
+    whose limits are the ones reported here."""
     n = np.diff(csr["offsets"])[rows]
     max_rows = int(lib.lcfe_max_points())
-    if set_name in ("bazin", "powerlaw"):
-        over_rows = int((n > max_rows).sum())
-        parts = []
-        if over_rows:
-            parts.append(f"{over_rows} with more than {max_rows} rows")
-        if len(rows) - over_rows:
-            what = "a band of more than 256 rows" if set_name == "bazin" else "more than 256 post-peak rows in a band"
-            parts.append(f"{len(rows) - over_rows} with {what} inside a light curve of more than 1024 rows")
-        return ", ".join(parts)
-    if set_name == "gp2d":
-        return f"more than {int(lib.lcfe_gp2d_max_points())} valid points"
-    if set_name == "gp1d":
-        return "a band of more than 767 valid points or more than 767 rows"
-    if set_name == "research":
-        return "an r band spanning more than the Mexican-hat grid of the kernel (status -100)"
-    return f"more than {max_rows} rows"
+    over_rows = int((n > max_rows).sum())
+    parts = [f"{over_rows} with more than {max_rows} rows"] if over_rows else []
+    rest = len(rows) - over_rows
+    if rest:
+        if set_name == "gp2d":
+            parts.append(f"{rest} with more than {int(lib.lcfe_gp2d_max_points())} valid points")
+        elif set_name == "gp1d":
+            parts.append(f"{rest} with a band of more than 767 valid points or more than 767 rows")
+        elif set_name == "research":
+            parts.append(f"{rest} whose r band spans more than 65536 days (the Mexican-hat grid of the long-object tier)")
+        else:
+            parts.append(f"{rest} beyond a tier limit")
+    return ", ".join(parts)
 
 
 def _warn_limits(names, csr, kept, status, lib):

@@ -46,23 +46,44 @@ def test_seeded_vs_oracle(name):
 
 @pytest.mark.parametrize("name", SETS)
 def test_lds_tiers_and_long_objects(name):
-    """Objects of 100..2048 points exercise every LDS tier; > 2048 points (1024 for the research set) -> NaN row
-    (documented)."""
+    """Objects of 100..2048 points exercise every LDS tier; longer ones (the reference has no cap: statistical.py:41-132,
+    research_features.py:163-430) take the long-object tier, whose working set lives in global scratch -- up to 16384
+    rows; beyond that a NaN row (documented)."""
     rng = np.random.default_rng(5)
     objs = []
-    for n in (100, 128, 129, 256, 257, 500, 512, 513, 1000, 1024, 1500, 2048, 2049, 3000):
+    for n in (100, 128, 129, 256, 257, 500, 512, 513, 1000, 1024, 1500, 2048, 2049, 3000, 5000, 16385):
         t = np.sort(59000 + rng.uniform(0, 800, n))
         f = 30 * np.exp(-0.5 * ((t - 59300) / 40) ** 2) + rng.normal(0, 1, n)
         objs.append((t, f, np.full(n, 1.0), rng.choice(6, n)))
     lc = synth.from_objects(objs)
     got = extract_csr(name, lc, z=lc["z"])
-    n_ok = 10 if name == "research" else 12        # the research set's largest tier is 1024 rows (32 KiB MHPS grid in LDS)
+    n_ok = len(objs) - 1
     sub = {k: (v[:lc["offsets"][n_ok]] if k in ("t", "flux", "err", "band") else v) for k, v in lc.items()}
     sub["offsets"] = lc["offsets"][:n_ok + 1]
     ref = oracle.extract(name, sub, lc["z"][:n_ok])
     bad = parity.compare(got[:n_ok], ref, COLUMNS[name], int_cols=INT.get(name, ()), label=name, **TOL[name])
     assert not bad, "\n".join(bad)
     assert np.isnan(got[n_ok:]).all()
+
+
+def test_research_long_r_band_span_takes_the_long_tier():
+    """An r band spanning more than 4096 days does not fit the Mexican-hat grid of the LDS tiers (32 KiB); the light
+    curve is handed to the long-object tier (64 Ki-day grid in global scratch) instead of coming back as NaN with
+    status -100 (research_features.py:352-430 has no limit)."""
+    rng = np.random.default_rng(8)
+    objs = []
+    for n, span in ((150, 300.0), (200, 5000.0), (900, 9000.0), (60, 70000.0)):
+        t = np.sort(50000 + rng.uniform(0, span, n))
+        b = rng.choice(6, n, p=[.05, .1, .4, .2, .15, .1])
+        f = 20 + 5 * np.sin((t - 50000) / 37.0) + rng.normal(0, 1, n)
+        objs.append((t, f, np.full(n, 0.8), b))
+    lc = synth.from_objects(objs)
+    got, st = extract_csr("research", lc, z=lc["z"], return_status=True)
+    assert (st[:3, 0] == 0).all() and st[3, 0] == -100        # 70000 days: beyond the long tier's grid as well
+    keep = synth.from_objects(objs[:3])
+    ref = oracle.extract("research", keep, lc["z"][:3])
+    bad = parity.compare(got[:3], ref, COLUMNS["research"], label="research", **TOL["research"])
+    assert not bad, "\n".join(bad)
 
 
 def test_statistics_band_shapes():
@@ -350,20 +371,24 @@ def test_gp2d_vs_oracle(golden_inputs):
 
 
 def test_gp2d_long_objects_use_global_tier():
+    """Gram-matrix tiers by length: LDS (60, 130), global scratch (191, 400, 600), and -- multiband_gp.py:66 only asks
+    for N >= 10 -- the long-object tier for light curves of more than 767 rows (800, 1200: Gram matrix AND working set in
+    global scratch).  2100 valid points are beyond it: NaN row, status -100."""
     rng = np.random.default_rng(3)
     objs = []
-    for n in (60, 130, 191, 400, 600, 800):      # 800 > the 767-row limit: NaN row, status -100
+    for n in (60, 130, 191, 400, 600, 800, 1200, 2100):
         t = np.sort(59000 + rng.uniform(0, 300, n))
         b = rng.choice(6, n)
         f = 30 * np.exp(-0.5 * ((t - 59100) / 30) ** 2) * (1 + 0.1 * b) + rng.normal(0, 1, n)
         objs.append((t, f, np.full(n, 1.0), b))
     lc = synth.from_objects(objs)
     got, st = extract_csr("gp2d", lc, return_status=True)
-    assert np.isnan(got[5]).all() and st[5, 0] == -100
-    assert not np.isnan(got[:5, :3]).any()
-    keep = synth.from_objects(objs[:5])
+    assert np.isnan(got[7]).all() and st[7, 0] == -100
+    assert not np.isnan(got[:7, :3]).any()
+    assert (st[:7, 3] == [60, 130, 191, 400, 600, 800, 1200]).all()
+    keep = synth.from_objects(objs[:7])
     ref = oracle.extract("gp2d", keep)
-    bad = parity.compare(got[:5], ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
+    bad = parity.compare(got[:7], ref, COLUMNS["gp2d"], rtol=1e-4, atol=1e-9)
     assert len(bad) <= 2, "\n".join(bad)
 
 
@@ -498,42 +523,49 @@ def test_device_batch_validates_out_and_status_buffers():
 
 
 def test_over_long_objects_are_reported_not_silent():
-    """The DataFrame wrappers warn (count + ids) about objects beyond a set's largest tier: their NaN rows would
-    otherwise look like failed fits (the reference has no such limit)."""
+    """The DataFrame wrappers warn (count, cause and ids) about objects beyond the long-object tier (16384 rows): their
+    NaN rows would otherwise look like failed fits (the reference has no limit at all)."""
     from mallorn_astrophysics_amd.features.bazin_fitting import extract_bazin_features
     rng = np.random.default_rng(12)
     objs = []
-    for n in (60, 2100):                     # Bazin takes light curves of up to 2048 rows
+    for n in (60, 2100, 16500):              # 2100 rows: long-object tier; 16500: beyond it
         t = np.sort(59000 + rng.uniform(0, 400, n))
         objs.append((t, rng.normal(10, 3, n), np.full(n, 1.0), rng.choice(6, n)))
     lc = synth.from_objects(objs)
-    df, _ = synth.to_dataframe(lc, ["short", "long"])
-    with pytest.warns(RuntimeWarning, match="long"):
-        out = extract_bazin_features(df, ["short", "long"])
-    assert np.isnan(out[COLUMNS["bazin"]].to_numpy(float)[1]).all()
+    df, _ = synth.to_dataframe(lc, ["short", "long", "huge"])
+    with pytest.warns(RuntimeWarning, match="huge"):
+        out = extract_bazin_features(df, ["short", "long", "huge"])
+    vals = out[COLUMNS["bazin"]].to_numpy(float)
+    assert np.isnan(vals[2]).all() and not np.isnan(vals[1]).all()
 
 
 def test_bazin_long_light_curves_vs_oracle():
-    """Light curves of 1025..2048 rows used to come back as NaN (the object-level kernel keeps a whole light curve in
-    LDS); the fit-by-fit path only needs one BAND (up to 256 rows) in LDS, so they are fitted like the reference does
-    (bazin_fitting.py:76-93 has no cap)."""
+    """Light curves of more than 1024 rows: the fit-by-fit path only needs one BAND (up to 256 rows) in LDS; a light
+    curve with a longer band, or of more than 2048 rows, is fitted by the long-object tier (object-level kernel, working
+    set in global scratch) -- bazin_fitting.py:76-93 has no cap."""
     rng = np.random.default_rng(31)
     objs = []
-    for n in (1100, 1530, 2046):             # <= 184, <= 256 and 341 rows per band: the last one exceeds the 256-row tier
+    for n in (1100, 1530, 2046, 2600):       # <= 184, <= 256 and 341 / 434 rows per band: the last two exceed the 256-row fit tier -> long-object tier
         t = np.sort(59000 + rng.uniform(0, 600, n))
         b = rng.permutation(np.repeat(np.arange(6), n // 6 + 1)[:n])
         f = 40 * np.exp(-(t - 59200) / 60) / (1 + np.exp(-(t - 59200) / 8)) * (1 + 0.1 * b) + 3 + rng.normal(0, 1.5, n)
         objs.append((t, f, np.full(n, 1.5), b))
     lc = synth.from_objects(objs)
     got, st = extract_csr("bazin", lc, return_status=True)
-    assert np.isnan(got[2]).all() and (st[2] == -100).all()
-    keep = synth.from_objects(objs[:2])
-    ref = oracle.extract("bazin", keep)
-    assert np.array_equal(np.isnan(got[:2]), np.isnan(ref))
+    ref = oracle.extract("bazin", lc)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
     both = ~np.isnan(ref)
-    rel = np.abs(got[:2] - ref)[both] / np.maximum(np.abs(ref[both]), 1e-9)
+    rel = np.abs(got - ref)[both] / np.maximum(np.abs(ref[both]), 1e-9)
     assert (rel <= 1e-4).mean() >= 0.9, (rel <= 1e-4).mean()
-    assert (st[:2, 0::2] > 0).all()
+    assert (st[:, 0::2] > 0).all()
+    # the decline fits of the same light curves (train_v55_powerlaw.py:161-163 has no cap either)
+    gotp, stp = extract_csr("powerlaw", lc, return_status=True)
+    refp = oracle.extract("powerlaw", lc)
+    assert np.array_equal(np.isnan(gotp), np.isnan(refp))
+    bothp = ~np.isnan(refp)
+    relp = np.abs(gotp - refp)[bothp] / np.maximum(np.abs(refp[bothp]), 1e-9)
+    assert (relp <= 1e-4).mean() >= 0.9, (relp <= 1e-4).mean()
+    assert (stp != -100).all()
 
 
 def test_all_ten_sets_in_one_call_equal_the_single_set_calls(golden_inputs):
