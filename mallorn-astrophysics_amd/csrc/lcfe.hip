@@ -349,8 +349,33 @@ int launch_long(const BatchView& B, const Bins& bins, int l0, int l1, int l2, do
 // longer bands (stat_lanes16.hpp: 16 lanes per light curve, up to 256 resp. 512 rows).  The lists' lengths are known
 // on the device only; the grid covers n_obj / 4 + 6 batches and the workgroups behind the last batch leave at once.  A light curve whose rows turn
 // out not to ascend in time is appended to list `retry`.
+#ifdef LCFE_DEBUG
+constexpr double kLanesCanary = 0x1.5ca1ab1edeadp+900;
+#endif
 __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins bins, int retry, double* out, int ld, int col0) {
+#ifdef LCFE_DEBUG
+    // debug build: canary words around the buffers, verified when the workgroup's batch is done
+    struct Framed { double pre[8]; StatLanesLds<32> L; double post[8]; };
+    __shared__ Framed F;
+    StatLanesLds<32>& L = F.L;
+    if (threadIdx.x < 8) { F.pre[threadIdx.x] = kLanesCanary; F.post[threadIdx.x] = kLanesCanary; }
+    __syncthreads();
+    unsigned int lanes_bad[2] = {0u, 0u};
+    struct CanaryCheck {
+        Framed& F;
+        unsigned int (&bad)[2];
+        __device__ ~CanaryCheck() {
+            __syncthreads();
+            if (threadIdx.x < 8 && (F.pre[threadIdx.x] != kLanesCanary || F.post[threadIdx.x] != kLanesCanary)) atomicAdd(&g_lanes_check[1], 1u);
+            if (bad[0]) { atomicAdd(&g_lanes_check[0], bad[0]); g_lanes_check[2] = bad[1]; }
+        }
+    } canary_check{F, lanes_bad};
+    unsigned int* const bad_p = lanes_bad;
+#else
     __shared__ StatLanesLds<32> L;
+    unsigned int* const bad_p = nullptr;
+#endif
+    const LanesBuf lbuf = lanes_buf(L.buf, 64 * StatLanesLds<32>::STRIDE, bad_p), lall = lanes_buf(L.all_rows, 8 * 17, bad_p);
     const int c16 = bins.counts[kStatL16List], c32 = bins.counts[kStatL32List], c32x = bins.counts[kStatL32xList];
     const int cw16 = bins.counts[kStatW16List], cw32 = bins.counts[kStatW32List];
     const int nb16 = (c16 + 7) >> 3, nb32 = (c32 + 7) >> 3, nb32x = (c32x + 7) >> 3, nbw16 = (cw16 + 3) >> 2, nbw32 = (cw32 + 3) >> 2;
@@ -359,26 +384,26 @@ __global__ __launch_bounds__(64, 2) void stat_lanes_all_kernel(BatchView B, Bins
     int* rc = &bins.counts[retry];
     // (the long batches first: they are the ones whose tail would otherwise stick out)
     if (b < nbw32) {
-        stat_lanes16_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW32List * bins.stride, cw32, b, L.buf,
-                                 L.all_rows, out, ld, col0, rl, rc);
+        stat_lanes16_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW32List * bins.stride, cw32, b, lbuf,
+                                 lall, out, ld, col0, rl, rc);
         return;
     }
     b -= nbw32;
     if (b < nbw16) {
-        stat_lanes16_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW16List * bins.stride, cw16, b, L.buf,
-                                 L.all_rows, out, ld, col0, rl, rc);
+        stat_lanes16_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatW16List * bins.stride, cw16, b, lbuf,
+                                 lall, out, ld, col0, rl, rc);
         return;
     }
     b -= nbw16;
     if (b < nb32x)
-        stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, L.buf, L.all_rows, out, ld,
+        stat_lanes_run<32, 32>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32xList * bins.stride, c32x, b, lbuf, lall, out, ld,
                                col0, rl, rc);
     else if (b < nb32x + nb32)
-        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb32x, L.buf, L.all_rows, out,
+        stat_lanes_run<32, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL32List * bins.stride, c32, b - nb32x, lbuf, lall, out,
                                ld, col0, rl, rc);
     else if (b < nb32x + nb32 + nb16)
-        stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b - nb32x - nb32, L.buf,
-                               L.all_rows, out, ld, col0, rl, rc);
+        stat_lanes_run<16, 16>(B.offsets, B.t, B.f, B.e, B.b, bins.lists + (int64_t)kStatL16List * bins.stride, c16, b - nb32x - nb32, lbuf,
+                               lall, out, ld, col0, rl, rc);
 }
 
 // Which statistics kernel takes a light curve of up to 512 rows: ONE launch over the three tier lists (128 / 256 / 512
@@ -1641,6 +1666,18 @@ int lcfe_debug_trf_prof(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lcfe::g_trf_prof), 64) != hipSuccess) return 1;
     unsigned long long z[8] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(lcfe::g_trf_prof), z, 64) != hipSuccess) return 1;
+    return 0;
+}
+#endif
+
+#ifdef LCFE_DEBUG
+// debug builds only: read and reset the counters of the bounds-checked lanes kernels
+// (out4: indices outside the LDS buffer, damaged canary words, the last bad index, the length of its buffer)
+int lcfe_debug_lanes_check(unsigned int* out4) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(lcfe::g_lanes_check), 16) != hipSuccess) return 1;
+    unsigned int z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lcfe::g_lanes_check), z, 16) != hipSuccess) return 1;
     return 0;
 }
 #endif

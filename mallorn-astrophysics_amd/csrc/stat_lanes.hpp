@@ -122,6 +122,41 @@ __device__ __forceinline__ void lane_merge(double (&w)[N], int lane_in_group) {
     reg_half_cleaners<N, N / 2>(w);
 }
 
+// The lanes kernels index one LDS buffer with computed slots (band position tables, merge dumps, the output rows).
+// Release builds use the plain pointer.  A -DLCFE_DEBUG build (make debug; SURVEY.md section 5 "sanitizer" row: the GPU
+// AddressSanitizer is not available on this pool) replaces it by a bounds-checked view: an index outside the buffer is
+// counted in g_lanes_check[0] (the access is redirected to slot 0 instead of faulting), and the kernel frames the buffer
+// with canary words it verifies before it ends (g_lanes_check[1]).  lcfe_debug_lanes_check() reads the counters.
+#ifdef LCFE_DEBUG
+__device__ unsigned int g_lanes_check[4];      // out-of-range indices, damaged canaries, last bad index, its buffer length
+// (branch-free: a bad index is clamped to slot 0 and counted in a per-lane register the kernel flushes when it ends --
+//  hundreds of inlined divergent branches around the accesses changed the code the compiler produced for the rest)
+struct LanesBuf {
+    double* p;
+    int n;
+    unsigned int* bad;      // per-lane counter (a register of the kernel), [1] = last bad index
+    __device__ __forceinline__ double& operator[](int i) const {
+        const bool oob = (unsigned int)i >= (unsigned int)n;
+        bad[0] += oob ? 1u : 0u;
+        bad[1] = oob ? (unsigned int)i : bad[1];
+        return p[oob ? 0 : i];
+    }
+    __device__ __forceinline__ LanesBuf operator+(int k) const { return LanesBuf{p + k, n - k, bad}; }
+};
+__device__ __forceinline__ LanesBuf lanes_buf(double* p, int n, unsigned int* bad) { return LanesBuf{p, n, bad}; }
+// plain pointer to `count` doubles of the view, for the helpers that take one (the range is checked once)
+__device__ __forceinline__ double* lanes_raw(const LanesBuf& b, int count) {
+    const bool oob = count > b.n || b.n < 0;
+    b.bad[0] += oob ? 1u : 0u;
+    b.bad[1] = oob ? (unsigned int)count : b.bad[1];
+    return b.p;
+}
+#else
+using LanesBuf = double*;
+__device__ __forceinline__ LanesBuf lanes_buf(double* p, int, unsigned int*) { return p; }
+__device__ __forceinline__ double* lanes_raw(LanesBuf b, int) { return b; }
+#endif
+
 template <int CAP>
 struct StatLanesLds {
     static constexpr int STRIDE = CAP + 1;       // odd number of doubles: a column per lane without bank conflicts
@@ -131,14 +166,14 @@ struct StatLanesLds {
 
 // element `idx` of an ascending sequence dumped lane-major from column `base` on (CAP registers per lane)
 template <int CAP>
-__device__ __forceinline__ double lanes_seq(const double* buf, int base, int idx) {
+__device__ __forceinline__ double lanes_seq(LanesBuf buf, int base, int idx) {
     constexpr int SH = (CAP == 16) ? 4 : ((CAP == 32) ? 5 : 6);
     return buf[base + idx + (idx >> SH)];
 }
 
 // median, inter-quartile range and MAD of the ascending NaN-free sequence of m >= 1 values at `base`
 template <int CAP>
-__device__ __forceinline__ void lanes_order_stats(const double* buf, int base, int m, double& med, double& iqr, double& mad) {
+__device__ __forceinline__ void lanes_order_stats(LanesBuf buf, int base, int m, double& med, double& iqr, double& mad) {
     auto S = [&](int i) { return lanes_seq<CAP>(buf, base, i); };
     const int r_lo = (m - 1) / 2, r_hi = m / 2;
     const double v25 = 0.25 * (m - 1), v75 = 0.75 * (m - 1);
@@ -179,7 +214,7 @@ __device__ __forceinline__ int lanes_pair(int x) { return lane_xor_fetch<1>(x); 
 // registers (profiles/r02_stat_instruction_budget.md).
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double* gf, const double* ge, const uint8_t* gb, int obj,
-                                              int64_t s1, int64_t e1, double* buf, double* all_rows, double* out, int ld, int col0,
+                                              int64_t s1, int64_t e1, LanesBuf buf, LanesBuf all_rows, double* out, int ld, int col0,
                                               int* fallback_list, int* fallback_count) {
     using G = GroupDev<8>;
     constexpr int STRIDE = StatLanesLds<CAP>::STRIDE;
@@ -376,7 +411,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         snan = snan | (p_snan != 0);
     }
     const double mean = s / mband, meanA = sA / N;
-    double* oa = all_rows + (g8 >> 3) * 17;              // the all-rows columns leave the registers as soon as they are known
+    LanesBuf oa = all_rows + (g8 >> 3) * 17;              // the all-rows columns leave the registers as soon as they are known
     if (j == 3) {
         oa[0] = (double)N;
         oa[1] = meanA;
@@ -513,10 +548,10 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
     }
 
     // ---- the 123 columns of every light curve -> LDS rows -> global
-    double* o = buf + (g8 >> 3) * 128;
+    LanesBuf o = buf + (g8 >> 3) * 128;
     if (fit) {
         if (!split || first) {
-            double* ob = o + 17 * band;
+            double* ob = lanes_raw(o + 17 * band, 17);
             if (mband == 0) stat_empty_group(ob, nullptr);
             else stat_write17(ob, mband, mean, sd, mn, mx, med, skew, kurt, mad, iqr, b1, b2, slope, snan, snr, nsnr, tmn, tmx);
         }
@@ -527,7 +562,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         for (int c = j; c < 17; c += 8) o[102 + c] = oa[c];
     }
     G::sync();
-    if (fit && j == 0) stat_cross_band(o);
+    if (fit && j == 0) stat_cross_band(lanes_raw(o, STAT_NCOL));
     G::sync();
     // rows to global memory, one light curve at a time on the whole wavefront (two 512-byte stores per row)
     const bool done = fit && orderedA;
@@ -536,7 +571,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
         const int obj_r = __builtin_amdgcn_readlane(done ? obj : -1, 8 * r);
         if (obj_r >= 0) {
             double* row = out + (int64_t)obj_r * ld + col0;
-            const double* src = buf + r * 128;
+            LanesBuf src = buf + r * 128;
             row[lane] = src[lane];
             if (lane + 64 < STAT_NCOL) row[lane + 64] = src[lane + 64];
         }
@@ -551,7 +586,7 @@ __device__ __forceinline__ void stat_lanes_batch(const double* gt, const double*
 // One workgroup = one batch (`batch`) of eight consecutive list entries; `buf`: 64 x (CAP + 1) doubles of LDS.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes_run(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
-                                               const uint8_t* gb, const int* list, int count, int batch, double* buf, double* all_rows,
+                                               const uint8_t* gb, const int* list, int count, int batch, LanesBuf buf, LanesBuf all_rows,
                                                double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
     const int g = (threadIdx.x & 63) >> 3;
     const int64_t base = (int64_t)batch * 8;

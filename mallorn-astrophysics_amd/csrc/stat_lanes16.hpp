@@ -48,7 +48,7 @@ __device__ __forceinline__ V lanes16_band(V x, bool four, Op op) {
 // `fallback_list`.  ITERS = rows / 16 a light curve of the list may have.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const double* gf, const double* ge, const uint8_t* gb, int obj,
-                                                   int64_t s1, int64_t e1, double* buf, double* all_rows, double* out, int ld,
+                                                   int64_t s1, int64_t e1, LanesBuf buf, LanesBuf all_rows, double* out, int ld,
                                                    int col0, int* fallback_list, int* fallback_count) {
     using G = Lanes16;
     constexpr int STRIDE = StatLanesLds<CAP>::STRIDE;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const doubl
     tmn = lanes16_band((m > 0) ? tmn : __builtin_inf(), four, mno);
     tmx = lanes16_band((m > 0) ? tmx : -__builtin_inf(), four, mxo);
     const double mean = s / mband, meanA = sA / N;
-    double* oa = all_rows + (g16 >> 4) * 17;              // the all-rows columns leave the registers as soon as they are known
+    LanesBuf oa = all_rows + (g16 >> 4) * 17;              // the all-rows columns leave the registers as soon as they are known
     if (j == 1) {
         oa[0] = (double)N;
         oa[1] = meanA;
@@ -387,9 +387,9 @@ __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const doubl
     if (mband <= 1) iqr = 0.0;                               // statistical.py:86: 0 unless the group has two rows
 
     // ---- the 123 columns of every light curve -> LDS rows -> global
-    double* o = buf + (g16 >> 4) * 128;
+    LanesBuf o = buf + (g16 >> 4) * 128;
     if (fit && first) {
-        double* ob = o + 17 * band;
+        double* ob = lanes_raw(o + 17 * band, 17);
         if (mband == 0) stat_empty_group(ob, nullptr);
         else stat_write17(ob, mband, mean, sd, mn, mx, med, skew, kurt, mad, iqr, b1, b2, slope, snan, snr, nsnr, tmn, tmx);
     }
@@ -399,7 +399,7 @@ __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const doubl
         for (int c = j; c < 17; c += 16) o[102 + c] = oa[c];
     }
     G::sync();
-    if (fit && j == 0) stat_cross_band(o);
+    if (fit && j == 0) stat_cross_band(lanes_raw(o, STAT_NCOL));
     G::sync();
     const bool done = fit && orderedA;
 #pragma unroll
@@ -407,7 +407,7 @@ __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const doubl
         const int obj_r = __builtin_amdgcn_readlane(done ? obj : -1, 16 * r);
         if (obj_r >= 0) {
             double* row = out + (int64_t)obj_r * ld + col0;
-            const double* src = buf + r * 128;
+            LanesBuf src = buf + r * 128;
             row[lane] = src[lane];
             if (lane + 64 < STAT_NCOL) row[lane + 64] = src[lane + 64];
         }
@@ -422,7 +422,7 @@ __device__ __forceinline__ void stat_lanes16_batch(const double* gt, const doubl
 // One workgroup = one batch (`batch`) of four consecutive list entries; `buf`: 64 x (CAP + 1) doubles of LDS.
 template <int CAP, int ITERS>
 __device__ __forceinline__ void stat_lanes16_run(const int64_t* offsets, const double* gt, const double* gf, const double* ge,
-                                                 const uint8_t* gb, const int* list, int count, int batch, double* buf, double* all_rows,
+                                                 const uint8_t* gb, const int* list, int count, int batch, LanesBuf buf, LanesBuf all_rows,
                                                  double* out, int ld, int col0, int* fallback_list, int* fallback_count) {
     const int g = (threadIdx.x & 63) >> 4;
     const int64_t base = (int64_t)batch * 4;

@@ -129,6 +129,14 @@ def test_statistics_band_shapes():
     assert not bad, "\n".join(bad)
 
 
+def lane_route_objects():
+    """The hand-made light curves of test_statistics_lane_routes (also fed to the bounds-checked debug build)."""
+    rng = np.random.default_rng(77)
+    objs = []
+    _lane_route_fill(objs, rng)
+    return objs, rng
+
+
 def test_statistics_lane_routes():
     """The eight- and four-light-curves-per-wavefront statistics kernels (stat_lanes.hpp, stat_lanes16.hpp): band lengths
     on both sides of every routing threshold of the plan kernels (16- / 32-row lanes, 8 / 16 lanes per light curve, r and i
@@ -136,9 +144,21 @@ def test_statistics_lane_routes():
     0 / 1 / 2 rows, odd and even r / i halves, negative and zero times, NaN and inf fluxes in either half, rows out of
     time order and unknown band codes inside lane-eligible light curves, and batch lengths that do not fill the last
     group of eight -- each object against the oracle, and the batch in a different order."""
-    rng = np.random.default_rng(77)
-    objs = []
+    objs, rng = lane_route_objects()
+    lc = synth.from_objects(objs)
+    got = extract_csr("stat", lc)
+    ref = oracle.extract("stat", lc)
+    bad = parity.compare(got, ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
+    assert not bad, "\n".join(bad)
+    # the same light curves in another order and another batch length (3 light curves in the last group of 8 -> 5)
+    order = rng.permutation(len(objs))[:-2]
+    lc2 = synth.from_objects([objs[i] for i in order])
+    got2 = extract_csr("stat", lc2)
+    key = lambda m: np.nan_to_num(m, nan=-7.25e300)
+    assert np.array_equal(key(got2), key(got[order])), "a light curve's statistics depend on its batch"
 
+
+def _lane_route_fill(objs, rng):
     def add(counts, t0=59000.0, nan_band=None, inf_band=None, shuffle=False, unknown=False, dup_t=False):
         n = int(sum(counts))
         t = np.sort(t0 + rng.uniform(0, 500, n))
@@ -187,17 +207,61 @@ def test_statistics_lane_routes():
     add([6, 6, 20, 21, 6, 6], unknown=True)               # general kernel
     add([30, 30, 60, 60, 30, 30], shuffle=True)
     add([30, 30, 60, 60, 30, 30], unknown=True)
-    lc = synth.from_objects(objs)
-    got = extract_csr("stat", lc)
-    ref = oracle.extract("stat", lc)
-    bad = parity.compare(got, ref, COLUMNS["stat"], int_cols=STAT_INT_COLUMNS, rtol=1e-9, atol=1e-12)
-    assert not bad, "\n".join(bad)
-    # the same light curves in another order and another batch length (3 light curves in the last group of 8 -> 5)
-    order = rng.permutation(len(objs))[:-2]
-    lc2 = synth.from_objects([objs[i] for i in order])
-    got2 = extract_csr("stat", lc2)
-    key = lambda m: np.nan_to_num(m, nan=-7.25e300)
-    assert np.array_equal(key(got2), key(got[order])), "a light curve's statistics depend on its batch"
+
+
+_DEBUG_CHILD = """
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from mallorn_astrophysics_amd import synth, _lib
+from mallorn_astrophysics_amd.engine import extract_csr
+from test_gpu_parity import lane_route_objects
+lib = _lib.load()
+objs, _ = lane_route_objects()
+a = extract_csr("stat", synth.from_objects(objs))
+b = extract_csr("stat", synth.make_lightcurves(6000, seed=4242))
+if hasattr(lib, "lcfe_debug_lanes_check"):
+    buf = (ctypes.c_uint * 4)()
+    assert lib.lcfe_debug_lanes_check(buf) == 0
+    print("LANES_CHECK", list(buf))
+np.savez({out!r}, a=a, b=b)
+"""
+
+
+def test_statistics_lanes_debug_build(tmp_path):
+    """SURVEY.md section 5, sanitizer row (the GPU AddressSanitizer is not available on this pool): the -DLCFE_DEBUG build
+    of the library (`make -C mallorn-astrophysics_amd/csrc debug`, built by __graft_entry__.build()) runs the statistics
+    lanes kernels -- 98 % of the survey's light curves, device-only code the host simulation cannot cover -- with every
+    LDS index range-checked and canary words around their buffers.  Fed with the hand-made routing cases and 6,000 seeded
+    light curves it must count no out-of-range index and no damaged canary, and return what the release build returns,
+    bit for bit."""
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    dbg = os.path.join(ROOT, "mallorn-astrophysics_amd", "csrc", "build", "liblcfe_debug.so")
+    if not os.path.exists(dbg):
+        pytest.skip("debug library not built (make -C mallorn-astrophysics_amd/csrc debug)")
+    outs = {}
+    for tag, env in (("debug", dict(os.environ, LCFE_LIB_PATH=dbg)), ("release", {k: v for k, v in os.environ.items() if k != "LCFE_LIB_PATH"})):
+        path = str(tmp_path / f"{tag}.npz")
+        code = _DEBUG_CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), out=path)
+        r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = (np.load(path), r.stdout)
+    line = [ln for ln in outs["debug"][1].splitlines() if ln.startswith("LANES_CHECK")]
+    assert line, "the debug library does not export lcfe_debug_lanes_check"
+    counts = eval(line[0].split(" ", 1)[1])
+    assert counts[0] == 0 and counts[1] == 0, f"out-of-range LDS indices / damaged canaries: {counts}"
+    for k in ("a", "b"):
+        d, r = outs["debug"][0][k], outs["release"][0][k]
+        diff = np.argwhere(~((d == r) | (np.isnan(d) & np.isnan(r))))
+        if len(diff):
+            with np.errstate(all="ignore"):
+                rel = np.abs(d - r) / np.maximum(np.abs(r), 1e-300)
+            print(f"set {k}: {len(diff)} entries differ between the debug and the release build, max rel {np.nanmax(rel):.3e}; first:",
+                  [(int(i), COLUMNS["stat"][j], float(d[i, j]), float(r[i, j])) for i, j in diff[:6]],
+                  "objects:", {int(i): int((diff[:, 0] == i).sum()) for i in np.unique(diff[:, 0])})
+        assert len(diff) == 0, f"{k}: debug and release builds disagree in {len(diff)} entries"
 
 
 def test_special_values_fuzz():
