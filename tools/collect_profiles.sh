@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the rocprofv3 summaries of a round on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 # kernel-trace/stats and the PMC counters are collected in SEPARATE rocprofv3 runs (the pool refuses combining them).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof_$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 """HBM traffic of one statistics pass from the rocprofv3 PMC files of tools/collect_profiles.sh:
-    python tools/stat_traffic.py r02  ->  profiles/r02_stat_traffic.json
+    python tools/stat_traffic.py r03  ->  profiles/r03_stat_traffic.json
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB (gfx950 correction of MI355X_MICROARCH.md), summed over the kernels of the
 statistics set and divided by the number of passes; the algorithmic bytes come from the bench line of the same round."""
 import collections
@@ -31,7 +31,7 @@ def per_pass(path, counter):
 
 
 def main():
-    r = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    r = sys.argv[1] if len(sys.argv) > 1 else "r03"
     prof = os.path.join(ROOT, "profiles")
     fetch, passes = per_pass(os.path.join(prof, f"{r}_stat_pmc_fetch_size.csv"), "FETCH_SIZE")
     write, _ = per_pass(os.path.join(prof, f"{r}_stat_pmc_write_size.csv"), "WRITE_SIZE")
