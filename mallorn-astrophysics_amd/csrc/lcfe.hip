@@ -982,8 +982,9 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
 }
 
 int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
-              int st_ld, int st0, hipStream_t stream, hipStream_t stream2, int dev, double* kscratch,
+              int st_ld, int st0, const hipStream_t* gs, int ngs, int dev, double* kscratch,
               size_t kscratch_bytes, int* n_launch, unsigned long long* tickets, char* long_slabs) {
+    hipStream_t stream = gs[0], stream2 = gs[(ngs > 1) ? 1 : 0];
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
     // spends 412-512 registers per lane on the unrolled tile passes and spills at 1024 threads.)
@@ -1002,7 +1003,7 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     for (int ti = last, pos = 0; ti >= 0; --ti, ++pos) {
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
         unsigned long long* tk = tickets + SET_GP2D * 8 + ti;
-        hipStream_t q = (pos & 1) ? stream2 : stream;
+        hipStream_t q = gs[pos % ngs];
         int rc = 0;
         switch (ti) {
             case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
@@ -1636,7 +1637,7 @@ int launch_stat(const BatchView& B, const Bins& bins, int64_t max_len, double* o
 bool set_implemented(int set) { return set >= 0 && set < NUM_SETS; }
 
 // Non-blocking side streams per device, created on first use and kept for the life of the process.
-constexpr int kSideStreams = 3;
+constexpr int kSideStreams = 5;       // [0] Bazin, [1] decline fits, [2] streaming sets + GP tiers, [3], [4] further GP tiers
 hipStream_t g_side[16][kSideStreams];
 bool g_side_ready[16] = {false};
 std::mutex g_side_mutex;
@@ -1883,7 +1884,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         for (int k = 0; k < NUM_SETS; ++k) { HIP_TRY(hipEventCreate(&ev0[k])); HIP_TRY(hipEventCreate(&ev1[k])); }
         E.ready = true;
     }
-    bool side_used[kSideStreams] = {false, false, false};
+    bool side_used[kSideStreams] = {false, false, false, false, false};
     int col0 = 0, st0 = 0, ne = 0;
     for (int s = 0; s < NUM_SETS; ++s) {
         if (!(mask & (1 << s))) continue;
@@ -1917,18 +1918,31 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             case SET_RESEARCH: rc = launch_set<SET_RESEARCH>(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, long_slab[s]); break;
             case SET_GP1D: rc = launch_gp1d(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, dev, &nl, tickets, gp1d_slab); break;
             case SET_GP2D:
-                if (fork && !side_used[2]) { HIP_TRY(hipStreamWaitEvent(side[2], forked, 0)); side_used[2] = true; }
-                rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, q, fork ? side[2] : q, dev, gp_scratch,
-                               gp_scratch_bytes, &nl, tickets, long_slab[s]);
-                // the set's stop event (prof) is recorded on q: make q wait for the tiers on the second stream
+            {
+                // the GP tiers, longest first, round-robin over the caller's stream and side streams 2.. (LCFE_GP_STREAMS, default
+                // 2: more streams start more tiers at once)
+                static const int want = [] { const char* e = getenv("LCFE_GP_STREAMS"); const int k = e ? atoi(e) : 2; return (k < 1) ? 1 : ((k > 4) ? 4 : k); }();
+                hipStream_t gs[4] = {q, q, q, q};
+                int ngs = 1;
                 if (fork) {
+                    for (int k = 1; k < want; ++k) {
+                        gs[k] = side[1 + k];
+                        if (!side_used[1 + k]) { HIP_TRY(hipStreamWaitEvent(side[1 + k], forked, 0)); side_used[1 + k] = true; }
+                    }
+                    ngs = want;
+                }
+                rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, gs, ngs, dev, gp_scratch,
+                               gp_scratch_bytes, &nl, tickets, long_slab[s]);
+                // the set's stop event (prof) is recorded on q: make q wait for the tiers on the other streams
+                for (int k = 1; k < ngs && !rc; ++k) {
                     hipEvent_t half;
                     HIP_TRY(hipEventCreateWithFlags(&half, hipEventDisableTiming));
-                    HIP_TRY(hipEventRecord(half, side[2]));
+                    HIP_TRY(hipEventRecord(half, gs[k]));
                     HIP_TRY(hipStreamWaitEvent(q, half, 0));
                     (void)hipEventDestroy(half);
                 }
                 break;
+            }
         }
         if (rc) return rc;
         if (prof) { HIP_TRY(hipEventRecord(ev1[s], q)); prof->launches[s] = nl; }

@@ -1,44 +1,73 @@
-"""End-to-end example on one GPU: competition-layout CSV files -> C++ ingest -> all feature sets on
-the MI355X -> one DataFrame, with the wall time of every stage.  Usage: end_to_end.py [n_objects]"""
+"""End to end through the entry points on one GPU: competition-layout CSV files -> C++ ingest -> ONE engine call for
+the eight v34a / v55 feature sets (statistics, Bazin, decline fits, TDE, colours, shapes, physics, 2-D GP) -> the frames
+the caches are made of, with the wall time of every stage and the entry-point rate in light curves/s.
+
+    python tools/end_to_end.py [n_objects] [--script]
+
+--script also runs scripts/precompute_features.py itself on the data set (every cache, incl. the per-band GP and the
+research set) and reports its own wall time.  The numbers of a round are kept in profiles/rNN_end_to_end.txt."""
 import os
+import subprocess
 import sys
 import tempfile
 import time
 
 import numpy as np
-import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from mallorn_astrophysics_amd.columns import COLUMNS, SET_NAMES          # noqa: E402
-from mallorn_astrophysics_amd.engine import extract_csr                   # noqa: E402
-from mallorn_astrophysics_amd.packing import pack_lightcurves             # noqa: E402
-from mallorn_astrophysics_amd.utils.data_loader import load_lightcurves, load_lightcurves_csr, write_synthetic_dataset  # noqa: E402
+from mallorn_astrophysics_amd.features import extract_all                                      # noqa: E402
+from mallorn_astrophysics_amd.engine import extract_csr                                        # noqa: E402
+from mallorn_astrophysics_amd.packing import pack_lightcurves                                  # noqa: E402
+from mallorn_astrophysics_amd.utils.data_loader import (load_lightcurves, load_lightcurves_csr, load_metadata,  # noqa: E402
+                                                         write_synthetic_dataset)
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 20000
+SETS = ["stat", "bazin", "powerlaw", "tde", "color", "shape", "physics", "gp2d"]
 with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as root:
     t0 = time.perf_counter()
     write_synthetic_dataset(root, n_train=8, n_test=n, seed=5, n_splits=4)
     raw = os.path.join(root, "data", "raw")
     print(f"wrote a synthetic test split of {n} objects in {time.perf_counter() - t0:.1f} s", flush=True)
+    _, meta = load_metadata(raw)
+    ids = meta["object_id"].tolist()
 
     t0 = time.perf_counter()
-    csr, ids = load_lightcurves_csr("test", raw)
+    csr, file_ids = load_lightcurves_csr("test", raw)
     t_ingest = time.perf_counter() - t0
-    sets = [s for s in SET_NAMES if s != "physics"]          # physics needs the metadata redshift column
     extract_csr(["stat"], csr)                                # first call: library + context start-up
     t0 = time.perf_counter()
-    out = extract_csr(sets, csr)
+    frames = extract_all(csr=(csr, file_ids), metadata=meta, object_ids=ids, sets=SETS)
     t_gpu = time.perf_counter() - t0
-    cols = [c for s in sets for c in COLUMNS[s]]
-    frame = pd.DataFrame(out, columns=cols)
-    frame.insert(0, "object_id", ids)
-    print(f"C++ ingest {t_ingest:.2f} s ({len(ids) / t_ingest:,.0f} light curves/s), GPU features {t_gpu:.2f} s "
-          f"({len(ids) / t_gpu:,.0f} light curves/s incl. PCIe), frame {frame.shape}", flush=True)
+    ncol = sum(len(f.columns) - 1 for f in frames.values())
+    print(f"C++ ingest {t_ingest:.2f} s ({len(ids) / t_ingest:,.0f} light curves/s); extract_all, eight sets / {ncol} columns in ONE "
+          f"engine call: {t_gpu:.2f} s = {len(ids) / t_gpu:,.0f} light curves/s through the entry point (PCIe and frames included); "
+          f"ingest + features {len(ids) / (t_ingest + t_gpu):,.0f} light curves/s", flush=True)
 
+    # the same frames the way round 2 made them: one pack and one engine call per extractor
     t0 = time.perf_counter()
-    ref_csr, ref_ids = pack_lightcurves(load_lightcurves("test", raw))
+    lc_frame = load_lightcurves("test", raw)
     t_pandas = time.perf_counter() - t0
-    same = all(np.array_equal(csr[k].view(np.uint8), ref_csr[k].view(np.uint8)) for k in ref_csr) and ids == [str(i) for i in ref_ids]
-    print(f"pandas read_csv + concat + pack {t_pandas:.2f} s ({len(ids) / t_pandas:,.0f} light curves/s); identical CSR: {same}")
+    t0 = time.perf_counter()
+    for s in SETS:
+        pack_lightcurves(lc_frame, ids)
+        extract_all(lc_frame, metadata=meta, object_ids=ids, sets=[s])
+    t_each = time.perf_counter() - t0
+    print(f"pandas read_csv + concat {t_pandas:.2f} s ({len(ids) / t_pandas:,.0f} light curves/s); one pack + one engine call per extractor "
+          f"(eight calls): {t_each:.2f} s = {len(ids) / t_each:,.0f} light curves/s", flush=True)
+    ref_csr, ref_ids = pack_lightcurves(lc_frame)
+    same = all(np.array_equal(csr[k].view(np.uint8), ref_csr[k].view(np.uint8)) for k in ref_csr) and file_ids == [str(i) for i in ref_ids]
+    print("C++ reader and pandas route give the identical CSR batch:", same)
     assert same
+
+    if "--script" in sys.argv:
+        env = dict(os.environ, LCFE_DATA_ROOT=root)
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "precompute_features.py")], env=env, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if "light curves/s through the entry point" in ln]
+        print(f"scripts/precompute_features.py (all eight caches, ten sets, train + test): {dt:.2f} s wall; its own report:")
+        for ln in lines:
+            print("   " + ln.strip())
