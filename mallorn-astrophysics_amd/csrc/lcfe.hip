@@ -532,9 +532,10 @@ struct FitWs {
     int64_t fit_stride;
 };
 
+// (times and fluxes are read from the partition pass's copy in global memory -- L2-resident, 16 bytes per row and
+//  evaluation -- instead of a copy in LDS: 2.5 KB per fit at 32 rows instead of 3 KB = eight wavefronts per CU where six fitted)
 template <int BCAP>
 struct FitRegion {
-    double t[BCAP], f[BCAP];
     double r[BCAP], rn[BCAP], w[BCAP];     // rn doubles as the key scratch of the median before the first trial point
     double A[6][BCAP + 5];
     double slot[2];
@@ -653,17 +654,15 @@ __global__ __launch_bounds__(64, (fit_waves<BCAP>::N)) void bazin_fit_kernel(Bat
                 const int b0 = F.pboff[obj * 8 + band];
                 m = F.pboff[obj * 8 + band + 1] - b0;
                 src = B.offsets[obj] + b0;
-                for (int i = gl; i < m; i += 8) { Rg.t[i] = F.pt[src + i]; Rg.f[i] = F.pf[src + i]; }
-                G::sync();
-                bazin_prepare<G, TrfView<5>>(Rg.t, Rg.f, F.pe + src, m, V, Rg.slot, reinterpret_cast<unsigned long long*>(Rg.rn), Z);
-                trf_begin<G, BazinModel, TrfView<5>>(BazinModel(), Rg.t, Rg.f, m, Z, V);
+                bazin_prepare<G, TrfView<5>>(F.pt + src, F.pf + src, F.pe + src, m, V, Rg.slot, reinterpret_cast<unsigned long long*>(Rg.rn), Z);
+                trf_begin<G, BazinModel, TrfView<5>>(BazinModel(), F.pt + src, F.pf + src, m, Z, V);
             }
         }
         if (__ballot(Z.phase != FIT_EXIT) == 0ull) break;
         if (Z.phase == TRF_PH_OUTER) trf_outer<G, BazinModel, TrfView<5>>(m, Z, V);
-        if (Z.phase == TRF_PH_INNER) trf_inner<G, BazinModel, TrfView<5>>(BazinModel(), Rg.t, Rg.f, m, Z, V);
+        if (Z.phase == TRF_PH_INNER) trf_inner<G, BazinModel, TrfView<5>>(BazinModel(), F.pt + src, F.pf + src, m, Z, V);
         if (Z.phase == TRF_PH_DONE) {
-            bazin_finish<G>(Rg.t, Rg.f, F.pe + src, m, Z, out + obj * (int64_t)ld + col0 + 8 * band);
+            bazin_finish<G>(F.pt + src, F.pf + src, F.pe + src, m, Z, out + obj * (int64_t)ld + col0 + 8 * band);
             if (status && gl == 0) {
                 status[obj * (int64_t)st_ld + st0 + 2 * band] = Z.res.status;
                 status[obj * (int64_t)st_ld + st0 + 2 * band + 1] = Z.res.nfev;
@@ -704,6 +703,8 @@ struct PlWs {
     int64_t strideA, strideB;
 };
 
+// (the decline fits keep their rows in LDS: read from global memory their 32-row tiers ran 3-5 % slower -- LDS is not
+//  what limits their occupancy)
 template <int N, int BCAP>
 struct PlRegion {
     double t[BCAP], f[BCAP];
