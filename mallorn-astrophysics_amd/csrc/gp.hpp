@@ -955,6 +955,7 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
     double p[4] = {ymean, log(yvar / 2.0), log(100.0 * 100.0), log(6000.0 * 6000.0)};   // amp/ndim: george `float * kernel`
     bool finite0 = finite_d(p[0]) && finite_d(p[1]);
     double fval = 0;
+    double xe[4] = {qnan(), qnan(), qnan(), qnan()}, fe_last = 1e25;     // the point of the optimiser's last evaluation, its objective
     int n_iter = 0, n_eval = 0, why = LB_ERROR;
     if (finite0) {
         // the optimiser's state machine lives in LDS and is advanced by ONE thread between two barriers:
@@ -963,7 +964,9 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
         W::sync();
         for (;;) {
             double fe, ge[4];
+            xe[0] = S.lb.x[0]; xe[1] = S.lb.x[1]; xe[2] = S.lb.x[2]; xe[3] = S.lb.x[3];
             gp_ev(S.lb.x, n, fe, ge, true);
+            fe_last = fe;
             if (lane == 0) {
                 S.lb.f = fe;
                 S.lb.g[0] = ge[0]; S.lb.g[1] = ge[1]; S.lb.g[2] = ge[2]; S.lb.g[3] = ge[3];
@@ -1010,9 +1013,12 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
     }
     if (pk == 0x7fffffff) { W::sync(); return; }
     const double peak_time = L.t[pk] - tmin_all;
-    // ---- interpolate_multiband (:196-289): alpha at the optimum, then 12 predictions
-    double ftmp, gtmp[4];
-    gp_ev(p, n, ftmp, gtmp, false);
+    // ---- interpolate_multiband (:196-289): alpha at the optimum, then 12 predictions.  L-BFGS-B normally ends ON the
+    // point it evaluated last (the accepted end of its line search): S.alpha then already is K^-1 r at the optimum -- the
+    // same code computed it from the same inputs -- and the extra factorisation (one sweep in 26) is only paid when the
+    // optimiser stepped back to an earlier iterate.
+    double ftmp = fe_last, gtmp[4];
+    if (!(p[0] == xe[0] && p[1] == xe[1] && p[2] == xe[2] && p[3] == xe[3])) gp_ev(p, n, ftmp, gtmp, false);
     if (ftmp >= 1e25) { W::sync(); return; }          // factorisation failed at the optimum: predict raises -> NaN (:279-287)
     const double c = exp(p[1]), m0 = exp(p[2]), m1 = exp(p[3]);
     const double EP[4] = {0, 20, 50, 100};
