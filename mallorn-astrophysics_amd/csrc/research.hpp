@@ -308,15 +308,27 @@ LCFE_FN bool research_mhps(const double* t, const double* f, int m, ResearchLds<
         for (int k = lane; k < Lw; k += W::LANES) S.wv[k] /= norm;
         W::sync();
         // scipy.signal.convolve(f, w, mode='same'): out[i] = sum_j f[j] w[i + h - j], h = (Lw - 1) // 2
+        // Four consecutive outputs per lane: at step d the lane's outputs i0 + c need f[i0 + c + h - (Lw - 1) + d] and all
+        // lanes the same w[Lw - 1 - d], so one new grid value and one (broadcast) wavelet value serve four multiply-adds
+        // -- a quarter of the LDS reads of one output per lane.  Every output still adds its terms in ascending j; terms
+        // outside the grid enter as 0 * w, which leaves a sum unchanged (at most the sign of a zero, and the output is squared).
         const int h = (Lw - 1) / 2;
         double p2 = 0;
-        for (int i = lane; i < N; i += W::LANES) {
-            int j0 = i + h - (Lw - 1), j1 = i + h;
-            if (j0 < 0) j0 = 0;
-            if (j1 > N - 1) j1 = N - 1;
-            double acc = 0;
-            for (int j = j0; j <= j1; ++j) acc += S.grid[j] * S.wv[i + h - j];
-            p2 += acc * acc;
+        for (int base = 0; base < N; base += 4 * W::LANES) {
+            const int i0 = base + 4 * lane;
+            const int jb = i0 + h - (Lw - 1);                       // f index of output i0 at step 0
+            auto g_at = [&](int j) { return (j >= 0 && j < N) ? S.grid[j] : 0.0; };
+            double g0 = g_at(jb), g1 = g_at(jb + 1), g2 = g_at(jb + 2), g3 = g_at(jb + 3);
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int d = 0; d < Lw; ++d) {
+                const double wk = S.wv[Lw - 1 - d];
+                a0 += g0 * wk; a1 += g1 * wk; a2 += g2 * wk; a3 += g3 * wk;
+                g0 = g1; g1 = g2; g2 = g3; g3 = g_at(jb + d + 4);
+            }
+            if (i0 < N) p2 += a0 * a0;
+            if (i0 + 1 < N) p2 += a1 * a1;
+            if (i0 + 2 < N) p2 += a2 * a2;
+            if (i0 + 3 < N) p2 += a3 * a3;
         }
         pw[s] = W::sum(p2) / N;                                     // :413
         got[s] = true;
