@@ -984,7 +984,7 @@ int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, 
 
 int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out, int ld, int col0, int32_t* status,
               int st_ld, int st0, const hipStream_t* gs, int ngs, int dev, double* kscratch,
-              size_t kscratch_bytes, int* n_launch, unsigned long long* tickets, char* long_slabs, hipEvent_t first_tier_done = nullptr) {
+              size_t kscratch_bytes, int* n_launch, unsigned long long* tickets, char* long_slabs) {
     hipStream_t stream = gs[0], stream2 = gs[(ngs > 1) ? 1 : 0];
     // (A variant that keeps the matrix in the REGISTERS of the workgroup -- 2-D block-cyclic tiles,
     // register-tiled outer products -- was built and measured: slower on every tier, because hipcc
@@ -1016,12 +1016,11 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
             // enough for it and the other 64 let the fits overlap from the start -- +4.5 % light curves/s for the whole
             // step (75.2 k against 72.0 k, two runs each), where the GP on its own would lose 12 %
             case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_mid, tk,
-                                                        (stream2 != stream && !first_tier_done) ? 192 : 0); break;
+                                                        (stream2 != stream) ? 192 : 0); break;
             case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_glob, tk); break;
         }
         if (rc) return rc;
         ++*n_launch;
-        if (pos == 0 && first_tier_done) HIP_TRY(hipEventRecord(first_tier_done, q));
         // light curves of more than 767 rows (bin 6; NaN rows and status -100 from the launch above until this one has run)
         if (ti == last && last == 5 && long_slabs) {
             hipLaunchKernelGGL(gp_long_kernel, dim3(kGpLongGrid), dim3(gp_threads<kGpLongNP>::T), 0, q, B, bins, 6, out, ld, col0, status,
@@ -1887,27 +1886,9 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         E.ready = true;
     }
     bool side_used[kSideStreams] = {false, false, false, false, false};
-    // column / status offsets by set id; launch order: by id, or (LCFE_FITS_AFTER=1, experiment) the GP right after the
-    // statistics and the bounded fits only once its longest tier is done
-    int col_of[NUM_SETS], st_of[NUM_SETS];
-    {
-        int c = 0, t = 0;
-        for (int s = 0; s < NUM_SETS; ++s) { col_of[s] = c; st_of[s] = t; if (mask & (1 << s)) { c += set_ncols(s); t += set_nstatus(s); } }
-    }
-    static const bool fits_after = [] { const char* e = getenv("LCFE_FITS_AFTER"); return e && e[0] == '1'; }();
-    const bool gp_first = fits_after && fork && (mask & (1 << SET_GP2D));
-    int order[NUM_SETS], n_order = 0;
-    if (mask & (1 << SET_STAT)) order[n_order++] = SET_STAT;
-    if (gp_first) order[n_order++] = SET_GP2D;
-    for (int s = 1; s < NUM_SETS; ++s)
-        if ((mask & (1 << s)) && !(gp_first && s == SET_GP2D)) order[n_order++] = s;
-    Marker gp_marker;
-    hipEvent_t& gp_first_done = gp_marker.e;
-    if (gp_first) HIP_TRY(hipEventCreateWithFlags(&gp_first_done, hipEventDisableTiming));
-    int ne = 0;
-    for (int oi = 0; oi < n_order; ++oi) {
-        const int s = order[oi];
-        const int col0 = col_of[s], st0 = st_of[s];
+    int col0 = 0, st0 = 0, ne = 0;
+    for (int s = 0; s < NUM_SETS; ++s) {
+        if (!(mask & (1 << s))) continue;
         if (ne == 0) {
             // shared prologue (timed with the first set): zero tickets and counts, bin the objects
             if (prof) HIP_TRY(hipEventRecord(ev0[s], stream));
@@ -1925,7 +1906,6 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
             const int k = (q == side[0]) ? 0 : (q == side[1]) ? 1 : 2;
             if (!side_used[k]) { HIP_TRY(hipStreamWaitEvent(q, forked, 0)); side_used[k] = true; }
         }
-        if (gp_first && (s == SET_BAZIN || s == SET_POWERLAW)) HIP_TRY(hipStreamWaitEvent(q, gp_first_done, 0));
         if (prof && ne != 0) HIP_TRY(hipEventRecord(ev0[s], q));
         int nl = 0, rc = 0;
         switch (s) {
@@ -1953,7 +1933,7 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
                     ngs = want;
                 }
                 rc = launch_gp(B, bins, max_len, d_out, ld, col0, d_status, st_ld, st0, gs, ngs, dev, gp_scratch,
-                               gp_scratch_bytes, &nl, tickets, long_slab[s], gp_first ? gp_first_done : nullptr);
+                               gp_scratch_bytes, &nl, tickets, long_slab[s]);
                 // the set's stop event (prof) is recorded on q: make q wait for the tiers on the other streams
                 for (int k = 1; k < ngs && !rc; ++k) {
                     hipEvent_t half;
@@ -1968,6 +1948,8 @@ int lcfe_extract_device(int mask, int device, void* stream_, int64_t n_obj, int6
         if (rc) return rc;
         if (prof) { HIP_TRY(hipEventRecord(ev1[s], q)); prof->launches[s] = nl; }
         ++ne;
+        col0 += set_ncols(s);
+        st0 += set_nstatus(s);
     }
     // join the side streams back into the caller's stream
     for (int k = 0; k < kSideStreams; ++k) {
