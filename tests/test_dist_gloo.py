@@ -108,3 +108,25 @@ def test_gather_matches_single_process(tmp_path, world):
     lc = synth.make_lightcurves(37, seed=21)
     ref = oracle.extract("stat", lc, lc["z"])
     assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(ref, nan=-7.0))
+
+
+def _status_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lc = synth.make_lightcurves(23, seed=4)
+    bounds = shard_bounds(lc["offsets"], world, ["bazin"])
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    # status words travel like the feature rows: int32 blocks padded to the largest shard (with zeros, not NaN)
+    local = torch.arange(lo * 12, hi * 12, dtype=torch.int32).reshape(hi - lo, 12)
+    full = gather_rows(local, 23, bounds)
+    if rank == 0:
+        np.save(os.path.join(tmp, "status.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_int32_status_words(tmp_path):
+    mp.spawn(_status_worker, args=(3, 29537, str(tmp_path)), nprocs=3, join=True)
+    got = np.load(tmp_path / "status.npy")
+    assert got.dtype == np.int32 and np.array_equal(got, np.arange(23 * 12, dtype=np.int32).reshape(23, 12))

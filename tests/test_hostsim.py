@@ -68,3 +68,35 @@ def test_gp1d_templates_match_reference_golden(golden_inputs):
     both = ~np.isnan(ref)
     rel = np.abs(got - ref)[both] / np.maximum(np.abs(ref[both]), 1e-8)
     assert (rel <= 1e-4).mean() >= 0.97 and rel.max() <= 0.02, ((rel <= 1e-4).mean(), rel.max())
+
+
+@pytest.mark.parametrize("name", list(TOL))
+def test_long_object_tier_templates(name):
+    """The long-object tier runs the SAME templates with CAP = 16384 (working set in global scratch on the device):
+    compiled for the host at that capacity they must agree with the oracle on light curves of 2049 .. 5000 rows
+    (the device run of these objects is tests/test_gpu_parity.py::test_lds_tiers_and_long_objects)."""
+    import ctypes
+    import os
+    import subprocess
+    import oracle
+    from mallorn_astrophysics_amd import synth
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+    subprocess.run(["make", "-s", "-C", d, "libhostsim_long.so"], check=True)
+    rng = np.random.default_rng(5)
+    objs = []
+    for n in (2049, 3000, 5000):
+        t = np.sort(59000 + rng.uniform(0, 800, n))
+        f = 30 * np.exp(-0.5 * ((t - 59300) / 40) ** 2) + rng.normal(0, 1, n)
+        objs.append((t, f, np.full(n, 1.0), rng.choice(6, n)))
+    lc = synth.from_objects(objs)
+    saved = hostsim_lib._lib
+    try:
+        hostsim_lib._lib = ctypes.CDLL(os.path.join(d, "libhostsim_long.so"))
+        hostsim_lib._lib.hostsim_extract.restype = ctypes.c_int
+        assert hostsim_lib._lib.hostsim_max_points() == 16384
+        got, _ = hostsim_lib.extract(SET_NAMES.index(name), lc, lc["z"], ncol=len(COLUMNS[name]), nstatus=1)
+    finally:
+        hostsim_lib._lib = saved
+    ref = oracle.extract(name, lc, lc["z"])
+    bad = parity.compare(got, ref, COLUMNS[name], int_cols=STAT_INT_COLUMNS if name == "stat" else (), label=name, **TOL[name])
+    assert not bad, "\n".join(bad)
