@@ -970,7 +970,13 @@ LCFE_FN void gp_object(const ObjIn& L, LDS& S, Ev&& gp_ev, int32_t* st) {
             if (lane == 0) {
                 S.lb.f = fe;
                 S.lb.g[0] = ge[0]; S.lb.g[1] = ge[1]; S.lb.g[2] = ge[2]; S.lb.g[3] = ge[3];
-                S.lb_why = lb_advance(S.lb);
+#if defined(LCFE_GP_PROF) && defined(__HIPCC__)
+                const unsigned long long tlb = __builtin_readcyclecounter();
+#endif
+                S.lb_why = lb_advance<4, 10, LDS::kInLds>(S.lb);
+#if defined(LCFE_GP_PROF) && defined(__HIPCC__)
+                S.prof[9] += __builtin_readcyclecounter() - tlb;
+#endif
             }
             W::sync();
             if (S.lb_why != LB_EVAL) break;

@@ -18,6 +18,7 @@
 // The state machine is reverse-communication like the original: the caller evaluates f and g.
 // Everything here is wave/block-uniform scalar code (n = 4 parameters).
 #pragma once
+#include <type_traits>
 #include "wave.hpp"
 
 namespace lcfe {
@@ -185,6 +186,7 @@ struct LbState {
     double x[N], f, g[N];
     double d[N], t[N], r[N];
     double Sm[M][N], Ym[M][N], rho[M];      // circular memory of the (s, y) pairs
+    double al[M];                           // two-loop recursion: the first loop's coefficients
     double theta, fold, stp, gdold;
     double factr, pgtol;
     Dcsrch ls;
@@ -199,9 +201,25 @@ LCFE_FN void lb_start(LbState<N, M>& S, const double* x0, int maxiter, double fa
     S.maxiter = maxiter; S.maxls = maxls; S.factr = factr; S.pgtol = pgtol;
 }
 
+// member-wise copy of the line-search state between address spaces
+template <class A, class B>
+LCFE_FN void dcsrch_assign(A& a, const B& b) {
+    a.brackt = b.brackt; a.stage = b.stage;
+    a.ginit = b.ginit; a.gtest = b.gtest; a.gx = b.gx; a.gy = b.gy; a.finit = b.finit; a.fx = b.fx; a.fy = b.fy;
+    a.stx = b.stx; a.sty = b.sty; a.stmin = b.stmin; a.stmax = b.stmax; a.width = b.width; a.width1 = b.width1;
+}
+
 // One step of the state machine after an evaluation of (f, g) at S.x.  Scalar code (one thread).
-template <int N, int M>
-LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
+// IN_LDS (device): the caller's state is in LDS -- the function is not inlined, so without the address-space cast below
+// every access to it is a flat load / store (130 of them, measured 10-20 k cycles per call in the 2-D GP kernels).
+template <int N, int M, bool IN_LDS = false>
+LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using StateRef = typename std::conditional<IN_LDS, __attribute__((address_space(3))) LbState<N, M>, LbState<N, M>>::type;
+    StateRef& S = *(StateRef*)(&S0);
+#else
+    LbState<N, M>& S = S0;
+#endif
     double x[N], g[N], d[N];
     double f = S.f;
 #pragma unroll
@@ -222,7 +240,7 @@ LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) d[i] = -g[i] / S.theta;
             } else {
-                double q[N], al[M];
+                double q[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) q[i] = g[i];
                 for (int k = S.col - 1; k >= 0; --k) {
@@ -231,7 +249,7 @@ LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) a += S.Sm[idx][i] * q[i];
                     a *= S.rho[idx];
-                    al[k] = a;
+                    S.al[k] = a;
 #pragma unroll
                     for (int i = 0; i < N; ++i) q[i] -= a * S.Ym[idx][i];
                 }
@@ -244,7 +262,7 @@ LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
                     for (int i = 0; i < N; ++i) b += S.Ym[idx][i] * q[i];
                     b *= S.rho[idx];
 #pragma unroll
-                    for (int i = 0; i < N; ++i) q[i] += (al[k] - b) * S.Sm[idx][i];
+                    for (int i = 0; i < N; ++i) q[i] += (S.al[k] - b) * S.Sm[idx][i];
                 }
 #pragma unroll
                 for (int i = 0; i < N; ++i) d[i] = -q[i];
@@ -273,7 +291,10 @@ LCFE_FN_NOINLINE int lb_advance(LbState<N, M>& S) {
         }
         if (!ls_fail) {
             double stp = S.stp;
-            const int task = dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, S.first != 0, S.ls);
+            Dcsrch ls;
+            dcsrch_assign(ls, S.ls);
+            const int task = dcsrch(f, gd, stp, 1e-3, 0.9, 0.1, 0.0, stpmx, S.first != 0, ls);
+            dcsrch_assign(S.ls, ls);
             S.stp = stp;
             S.first = 0;
             if (task == LS_ERROR) ls_fail = true;

@@ -14,7 +14,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4242
 lc = synth.make_lightcurves(n, seed=seed)
 TOL = {"stat": dict(rtol=1e-9, atol=1e-12), "tde": dict(rtol=1e-8, atol=1e-8), "color": dict(rtol=1e-9, atol=1e-10),
-       "shape": dict(rtol=1e-8, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10)}
+       "shape": dict(rtol=1e-8, atol=1e-10), "physics": dict(rtol=1e-9, atol=1e-10),
+       "research": dict(rtol=1e-8, atol=1e-9)}
 INT = {"stat": [c for c in COLUMNS["stat"] if c.endswith("_n_obs") or c == "peak_band"]}
 
 _W = {}
@@ -46,7 +47,7 @@ def oracle_rows(name, n_w, seed_w):
         return np.concatenate(pool.map(work, jobs))
 
 if __name__ == "__main__":
-    for name in ("stat", "tde", "color", "shape", "physics"):
+    for name in ("stat", "tde", "color", "shape", "physics", "research"):
         t0 = time.time()
         got = extract_csr(name, lc, z=lc["z"])
         ref = oracle_rows(name, n, seed)
