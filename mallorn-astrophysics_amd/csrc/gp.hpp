@@ -30,6 +30,9 @@ LCFE_HD constexpr int gp_store_doubles(int np) { return ((np + 15) / 16) * ((np 
 
 #if defined(__HIPCC__)
 typedef __attribute__((address_space(3))) double lds_double;     // LDS-qualified element type: keeps ds_* addressing across calls
+// global-scratch matrix: without the qualifier the (not inlined) evaluation sees a generic pointer and every tile access is a
+// FLAT operation, which counts on the LDS counter as well -- each wait for an LDS read then also waits for the tile loads in flight
+typedef __attribute__((address_space(1))) double global_double;
 #endif
 
 template <class P> struct gp_is_lds_ptr { static constexpr bool value = false; };
@@ -496,7 +499,8 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                         }
                         const gp_v4f64 w1 = w_alayout(dA1, S.V, i);
                         const double n1[4] = {-w1[0], -w1[1], -w1[2], -w1[3]};
-                        constexpr int UNR = 2;      // tiles in flight (four were measured slower, also at 256 registers per lane)
+                        constexpr int UNR = 2;      // tiles in flight (four were measured slower, also at 256 registers per lane; so was
+                                                    // requesting the next trip's tiles ahead of this trip's products: +8 %, 11 more spilled registers)
                         for (int j0 = 0; j0 <= i; j0 += UNR) {
                             gp_v4f64 c[UNR];
                             double b1[UNR][4], b2v[UNR][4];
@@ -732,6 +736,9 @@ LCFE_FN double gp_kernel_q(double q0, double q1, double c, double& e) {
 // failed factorisation f = 1e25 and g = 0.  `need_grad` false: only alpha and f (prediction pass).
 template <class W, int NP, class KP, class LDS>
 LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, double* g, bool need_grad) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LDS::kInLds) __builtin_assume(__builtin_amdgcn_is_shared((const void*)&S));    // ds_* addressing of the working set
+#endif
     const int lane = W::lane();
     constexpr int G = (W::LANES >= 64) ? 64 : W::LANES;
     constexpr int RG = W::LANES / G;
@@ -831,6 +838,11 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
                 const int cj = (j << 4) + lc;
                 const double tj = S.t[cj], lj = S.sm.lam_at(cj), aj = S.alpha[cj];
                 KP T = K + tile_base(i, j);
+                // the tile's four entries of this lane in ONE round of loads ahead of the arithmetic (every tile (i, j <= i) has
+                // storage; a load inside the `in` arm below becomes a branch with its own wait per entry)
+                double tv[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tv[v] = T[((lr + 4 * v) << 4) + lc];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int r = (i << 4) + lr + 4 * v;
@@ -841,7 +853,8 @@ LCFE_FN_NOINLINE void gp_eval(const double* p, int n, LDS& S, KP K, double& f, d
                     const double q0 = dt * dt * im0, q1 = dl * dl * im1;
                     double e;
                     const double k = gp_kernel_q(q0, q1, c, e);
-                    const double a = in ? (ai[v] * aj + T[((lr + 4 * v) << 4) + lc]) * ((cj == r) ? 1.0 : 2.0) : 0.0;
+                    const double a_in = (ai[v] * aj + tv[v]) * ((cj == r) ? 1.0 : 2.0);
+                    const double a = in ? a_in : 0.0;
                     g1 += a * k;
                     g2 += a * e * q0;
                     g3 += a * e * q1;

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) voi
         ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
         if constexpr (GLOBAL_K) {
             gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
-                gp_eval<W, NP, double*>(x, n, S, Kg, f, g, need); }, st);
+                gp_eval<W, NP, global_double*>(x, n, S, (global_double*)Kg, f, g, need); }, st);
         } else {
             gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
                 gp_eval<W, NP, lds_double*>(x, n, S, (lds_double*)Klds, f, g, need); }, st);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(gp_threads<kGpLongNP>::T, 1) void gp_long_kernel(Ba
         int32_t* st = status ? status + i * (int64_t)st_ld + st0 : nullptr;
         ObjIn in{B.t + s, B.f + s, B.e + s, B.b + s, (int)n64, qnan()};
         gp_object<W, NP>(in, S, [&](const double* x, int n, double& f, double* g, bool need) {
-            gp_eval<W, NP, double*>(x, n, S, Kg, f, g, need); }, st);
+            gp_eval<W, NP, global_double*>(x, n, S, (global_double*)Kg, f, g, need); }, st);
         store_row<W>(S.out, out + i * (int64_t)ld + col0, GP_NCOL);
         __syncthreads();
     }
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(T, MW) void gp1d_kernel(BatchView B, Bins bins, int
                     const int b0 = boff[j], m = boff[j + 1] - b0;
                     gp1d_band<W, kGp1dLongNP>([&](int r, double& tt, double& ff, double& ee) { const int k = rows[b0 + r]; tt = t[k]; ff = f[k]; ee = e[k]; },
                                               m, LG,
-                                              [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, kGp1dLongNP, double*>(x, nn, LG, Kg, fv, gv); },
+                                              [&](const double* x, int nn, double& fv, double* gv) { gp1d_eval<W, kGp1dLongNP, global_double*>(x, nn, LG, (global_double*)Kg, fv, gv); },
                                               orow + 4 * j, st ? st + j : nullptr);
                     __syncthreads();
                 }
