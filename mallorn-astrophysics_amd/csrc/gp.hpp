@@ -388,6 +388,9 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                             c = __builtin_amdgcn_mfma_f64_16x16x4f64(-wt[kc], S.V[4 * kc + lr][(b << 4) + lc], c, 0, 0, 0);
 #pragma unroll
                         for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+                        // the second panel straight from the registers (what gather(V2, b) would read back from global scratch)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) V2[lc][(i << 4) + lr + 4 * v] = c[v];
                     }
                     // ---- ... and on tile row b, its b + 1 tiles dealt to all wavefronts
                     {
@@ -405,10 +408,19 @@ LCFE_FN bool gp_sweep_inverse(KP A, int n, LDS& S, double& logdet) {
                             }
 #pragma unroll
                             for (int v = 0; v < 4; ++v) T[((lr + 4 * v) << 4) + lc] = c[v];
+                            if (j < b) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) V2[lr + 4 * v][(j << 4) + lc] = c[v];
+                            } else {
+                                // the pivot block itself: V2[p][16 b + q] = A(16 b + q, 16 b + p) from the lower triangle, both ways
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    const int pp = lr + 4 * v;
+                                    if (lc <= pp) { V2[pp][(b << 4) + lc] = c[v]; V2[lc][(b << 4) + pp] = c[v]; }
+                                }
+                            }
                         }
                     }
-                    W::sync();
-                    gather(V2, b, GP_B);
                     W::sync();
                     if (!have2) { invert(V2, P2, k0 + GP_B, GP_B); W::sync(); }
                     if (S.pivot_bad != 0) return false;
