@@ -72,7 +72,7 @@ struct BatchView {
 // ---- binning: index lists per LDS tier (feature sets) and per Gram-matrix tier (GP)
 constexpr int kNumBins = 7;            // up to six tiers + "longer than the largest tier" (bin 6; the sets use bins 0..4 + 6)
 constexpr int kBinThreads = 1024;
-constexpr int kNumLists = 2 * kNumBins + 12;
+constexpr int kNumLists = 2 * kNumBins + 12 + 6;
 constexpr int kStatFallbackList = 2 * kNumBins;   // objects the lean statistics kernel hands to the general one
 constexpr int kBazinFallbackList = 2 * kNumBins + 1;   // objects with a band longer than the largest fit tier
 constexpr int kPowerlawFallbackList = 2 * kNumBins + 2;
@@ -85,6 +85,7 @@ constexpr int kStatW32List = 2 * kNumBins + 8;        // ... up to 512 rows, the
 constexpr int kBazinLongList = 2 * kNumBins + 9;      // light curves of more than 1024 rows with a band beyond the largest fit tier
 constexpr int kPowerlawLongList = 2 * kNumBins + 10;  // ... with more post-peak rows in a band than the largest fit tier
 constexpr int kResearchLongList = 2 * kNumBins + 11;  // light curves whose r band spans more days than the Mexican-hat grid in LDS
+constexpr int kGpSortedList = 2 * kNumBins + 12;      // + tier (0..5): the 2-D GP tier's light curves, longest first (gp_sort_kernel)
 struct Bins {
     int* lists;                        // [kNumLists][n_obj]: set tiers, GP tiers, statistics fallback
     int* counts;                       // [kNumLists]
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(gp_threads<NP>::T, (gp_waves<NP, GLOBAL_K>::N)) voi
     __shared__ long long next_ticket;
     double* Kg = kscratch + (size_t)blockIdx.x * (size_t)gp_store_doubles(NP);
     const int count = bins.counts[kNumBins + bin];
-    const int* list = bins.lists + (int64_t)(kNumBins + bin) * bins.stride;
+    const int* list = bins.lists + (int64_t)(kGpSortedList + bin) * bins.stride;      // longest first (gp_sort_kernel)
     for (;;) {
         if (threadIdx.x == 0) next_ticket = (long long)atomicAdd(ticket, 1ull);
         __syncthreads();
@@ -956,6 +957,51 @@ __global__ __launch_bounds__(gp_threads<kGpLongNP>::T, 1) void gp_long_kernel(Ba
     }
 }
 
+// The tickets of a GP tier are served longest light curve first: an evaluation costs ~N^3 and a run 10-100 evaluations, so
+// in file order the last tickets of a tier can be its most expensive light curves (a 500-row one is 60 ms on ONE workgroup
+// while the rest of the grid has drained; simulated on the bench shard, the 512-row tier ends 14 % after the ideal in file
+// order and 2 % after it longest first).  One workgroup per tier: counting sort of the tier's list by row count into the
+// tier's second list.  The order inside a row count is whatever the atomics give -- results do not depend on the order.
+constexpr int kGpSortThreads = 1024;
+__global__ __launch_bounds__(kGpSortThreads) void gp_sort_kernel(const int64_t* offsets, Bins bins) {
+    const int tier = blockIdx.x;
+    const int hi = (tier == 0) ? 63 : (tier == 1) ? 111 : (tier == 2) ? 159 : (tier == 3) ? kGpSmallNP - 1 : (tier == 4) ? kGpMidNP - 1 : kGpGlobalNP - 1;
+    const int count = bins.counts[kNumBins + tier];
+    const int* src = bins.lists + (int64_t)(kNumBins + tier) * bins.stride;
+    int* dst = bins.lists + (int64_t)(kGpSortedList + tier) * bins.stride;
+    __shared__ int hist[1024], wsum[kGpSortThreads / 64];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < count; k += kGpSortThreads) {
+        const int i = src[k];
+        const int key = hi - (int)(offsets[i + 1] - offsets[i]);             // 0 = the longest light curve the tier takes
+        atomicAdd(&hist[(key < 0) ? 0 : ((key > 1023) ? 1023 : key)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 counters: inside the wavefronts, then over the 16 wavefront totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mine = hist[threadIdx.x];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    __syncthreads();
+    hist[threadIdx.x] = before + incl - mine;
+    __syncthreads();
+    for (int k = threadIdx.x; k < count; k += kGpSortThreads) {
+        const int i = src[k];
+        const int key = hi - (int)(offsets[i + 1] - offsets[i]);
+        const int at = atomicAdd(&hist[(key < 0) ? 0 : ((key > 1023) ? 1023 : key)], 1);
+        dst[at] = i;
+    }
+}
+
 template <int NP, bool GLOBAL_K>
 int launch_gp_tier(const BatchView& B, const Bins& bins, int bin, int nan_from, double* out, int ld, int col0,
                    int32_t* status, int st_ld, int st0, hipStream_t stream, int dev, double* kscratch,
@@ -999,25 +1045,64 @@ int launch_gp(const BatchView& B, const Bins& bins, int64_t max_len, double* out
     double* k_glob = k_mid + kGpMidBytes / 8;
     double* k_112 = k_glob + kGpGlobalBytes / 8;
     double* k_160 = k_112 + kGp112Bytes / 8;
-    // longest objects first, tiers alternating between two streams: the heavy-tailed end of one tier
-    // (single objects of up to 50 ms) overlaps with the start of the next
-    for (int ti = last, pos = 0; ti >= 0; --ti, ++pos) {
+    // every tier's list longest light curve first (on the first GP stream; the others wait for it)
+    {
+        hipLaunchKernelGGL(gp_sort_kernel, dim3((unsigned)(last + 1)), dim3(kGpSortThreads), 0, gs[0], B.offsets, bins);
+        HIP_TRY(hipGetLastError());
+        ++*n_launch;
+        if (ngs > 1) {
+            hipEvent_t sorted;
+            HIP_TRY(hipEventCreateWithFlags(&sorted, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(sorted, gs[0]));
+            for (int k = 1; k < ngs; ++k) HIP_TRY(hipStreamWaitEvent(gs[k], sorted, 0));
+            (void)hipEventDestroy(sorted);
+        }
+    }
+    // Launch plan: which stream takes which tiers, in which order, and on how many workgroups at most.  Default (two GP
+    // streams): longest tier first, tiers alternating between the streams -- the heavy-tailed end of one tier (single objects
+    // of up to 50 ms) overlaps with the start of the next.  The 512-row tier holds a whole CU per workgroup (160 KB of LDS)
+    // for the first half second of the step and is bound by the MFMA pipe: when the fit kernels run beside the GP (side
+    // streams), 192 of the 256 CUs are enough for it and the other 64 let the fits overlap from the start -- +4.5 % light
+    // curves/s for the whole step (75.2 k against 72.0 k, two runs each), where the GP on its own would lose 12 %.
+    // LCFE_GP_PLAN overrides it for experiments: streams separated by '|', tiers (0 = 64 rows .. 5 = 768 rows) by ',', an
+    // optional ':cap' after a tier, e.g. "4:192,2,0|3,1" (the default with two streams).
+    struct PlanItem { int tier, stream; int64_t cap; };
+    PlanItem plan[12];
+    int n_plan = 0;
+    {
+        static const char* env = getenv("LCFE_GP_PLAN");
+        bool seen[6] = {false, false, false, false, false, false};
+        if (env && ngs > 1) {
+            int st = 0;
+            for (const char* c = env; *c && n_plan < 12;) {
+                if (*c == '|') { ++st; ++c; continue; }
+                if (*c == ',') { ++c; continue; }
+                if (*c < '0' || *c > '5') return fail_msg("lcfe_extract_device: malformed LCFE_GP_PLAN");
+                PlanItem it{*c - '0', (st < ngs) ? st : ngs - 1, 0};
+                ++c;
+                if (*c == ':') { it.cap = atoi(c + 1); ++c; while (*c >= '0' && *c <= '9') ++c; }
+                if (it.tier <= last && !seen[it.tier]) { seen[it.tier] = true; plan[n_plan++] = it; }
+            }
+        }
+        for (int ti = last, pos = 0; ti >= 0; --ti, ++pos) {
+            if (env && ngs > 1) { if (!seen[ti]) plan[n_plan++] = PlanItem{ti, 0, 0}; continue; }
+            plan[n_plan++] = PlanItem{ti, pos % ngs, (ti == 4 && stream2 != stream) ? 192 : 0};
+        }
+    }
+    for (int pi = 0; pi < n_plan; ++pi) {
+        const int ti = plan[pi].tier;
+        const int64_t cap = plan[pi].cap;
         const int nan_from = (ti == last) ? ti + 1 : kNumBins;
         unsigned long long* tk = tickets + SET_GP2D * 8 + ti;
-        hipStream_t q = gs[pos % ngs];
+        hipStream_t q = gs[plan[pi].stream];
         int rc = 0;
         switch (ti) {
-            case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk); break;
-            case 1: rc = launch_gp_tier<112, kGp112Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_112, tk); break;
-            case 2: rc = launch_gp_tier<160, kGp160Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_160, tk); break;
-            case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_small, tk); break;
-            // the 512-row tier holds a whole CU per workgroup (160 KB of LDS) for the first half second of the step and is
-            // bound by the MFMA pipe: when the fit kernels run beside the GP (side streams), 192 of the 256 CUs are
-            // enough for it and the other 64 let the fits overlap from the start -- +4.5 % light curves/s for the whole
-            // step (75.2 k against 72.0 k, two runs each), where the GP on its own would lose 12 %
-            case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_mid, tk,
-                                                        (stream2 != stream) ? 192 : 0); break;
-            case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_glob, tk); break;
+            case 0: rc = launch_gp_tier<64, false>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, nullptr, tk, cap); break;
+            case 1: rc = launch_gp_tier<112, kGp112Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_112, tk, cap); break;
+            case 2: rc = launch_gp_tier<160, kGp160Global>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_160, tk, cap); break;
+            case 3: rc = launch_gp_tier<kGpSmallNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_small, tk, cap); break;
+            case 4: rc = launch_gp_tier<kGpMidNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_mid, tk, cap); break;
+            case 5: rc = launch_gp_tier<kGpGlobalNP, true>(B, bins, ti, nan_from, out, ld, col0, status, st_ld, st0, q, dev, k_glob, tk, cap); break;
         }
         if (rc) return rc;
         ++*n_launch;
