@@ -1480,18 +1480,18 @@ int launch_bazin(const BatchView& B, const Bins& bins, int64_t max_len, double* 
         if (rc) return rc;
         ++*n_launch;
     }
-    int rc = launch_bazin_fits<256>(B, bins, F, 3, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 3);
+    // objects with a band of more than 256 rows: the object-level kernel (all 52 columns).  A small grid, and AHEAD of the
+    // fit tiers: the list is normally empty, but every workgroup of this kernel needs 136 KiB of LDS -- at the end of the
+    // stream it sat in the dispatcher for 100-180 ms, until a GP tier released a whole CU (tools/step_timeline.py)
+    int rc = launch_tier<SET_BAZIN, 1024>(B, bins, kBazinFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
+    if (rc) return rc;
+    ++*n_launch;
+    rc = launch_bazin_fits<256>(B, bins, F, 3, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 3);
     if (!rc) rc = launch_bazin_fits<128>(B, bins, F, 2, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 2);
     if (!rc) rc = launch_bazin_fits<64>(B, bins, F, 1, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 1);
     if (!rc) rc = launch_bazin_fits<32>(B, bins, F, 0, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kFitTicketBase + 0);
     if (rc) return rc;
     *n_launch += 4;
-    // objects with a band of more than 256 rows: the object-level kernel (all 52 columns)
-    // (a small grid: the list is normally empty, and every workgroup of this kernel needs 136 KiB of LDS -- a chip-wide
-    // grid would sit in the dispatcher until the GP tiers release whole CUs, holding up the rest of this stream)
-    rc = launch_tier<SET_BAZIN, 1024>(B, bins, kBazinFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
-    if (rc) return rc;
-    ++*n_launch;
     hipLaunchKernelGGL(bazin_cross_kernel, dim3((unsigned)((B.n_obj + 255) / 256)), dim3(256), 0, stream, B, out, ld, col0);
     HIP_TRY(hipGetLastError());
     ++*n_launch;
@@ -1575,7 +1575,10 @@ int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, doubl
         if (rc) return rc;
         ++*n_launch;
     }
-    int rc = 0;
+    // the object-level kernel for the (normally empty) list of objects beyond the fit tiers, AHEAD of the fit tiers: see launch_bazin
+    int rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
+    if (rc) return rc;
+    ++*n_launch;
 #define PL_TIER(BC, T)                                                                                                        \
     if (!rc) rc = launch_powerlaw_fits<2, BC>(B, bins, F, T, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kPlTicketA + T); \
     if (!rc) rc = launch_powerlaw_fits<3, BC>(B, bins, F, T, out, ld, col0, status, st_ld, st0, stream, dev, tickets + kPlTicketB + T);
@@ -1583,9 +1586,6 @@ int launch_powerlaw(const BatchView& B, const Bins& bins, int64_t max_len, doubl
 #undef PL_TIER
     if (rc) return rc;
     *n_launch += 8;
-    rc = launch_tier<SET_POWERLAW, 1024>(B, bins, kPowerlawFallbackList, kNumBins, out, ld, col0, status, st_ld, st0, stream, dev, tk + 5, 32);
-    if (rc) return rc;
-    ++*n_launch;
     if (long_slabs && max_len > 1024) {
         rc = launch_long<SET_POWERLAW>(B, bins, 6, kPowerlawLongList, -1, out, ld, col0, status, st_ld, st0, stream, tk + 7, long_slabs);
         if (rc) return rc;
