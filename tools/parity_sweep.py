@@ -46,7 +46,7 @@ def oracle_rows(name, n_w, seed_w):
     with pool:
         return np.concatenate(pool.map(work, jobs))
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.path.basename(sys.argv[0]) == "parity_sweep.py":
     for name in ("stat", "tde", "color", "shape", "physics", "research"):
         t0 = time.time()
         got = extract_csr(name, lc, z=lc["z"])
@@ -74,6 +74,6 @@ def fit_report(name, n_fit):
           f"{nan_mismatch} NaN-mask mismatches of {got.size} ({time.time() - t0:.0f}s)", flush=True)
 
 
-if __name__ == "__main__" and len(sys.argv) > 3:
+if __name__ == "__main__" and os.path.basename(sys.argv[0]) == "parity_sweep.py" and len(sys.argv) > 3:
     for name in sys.argv[3].split(","):
         fit_report(name, int(sys.argv[4]) if len(sys.argv) > 4 else 2000)
